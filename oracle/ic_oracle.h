@@ -1,0 +1,75 @@
+/* TEST INFRASTRUCTURE ONLY -- not part of the product, never linked into it.
+ *
+ * Plain-C CPU restatement of the per-block encode path of google/image-compression
+ * (DXT1/DXT5, ETC1, PVRTC1 2bpp).  It exists to (a) check the HIP kernels
+ * bit-for-bit on the GPU box, where /root/reference is absent, and (b) serve as
+ * the timed CPU baseline in bench.py (`cpu_baseline.kind = "port"`).
+ *
+ * PARITY PINNING: the reference ships no tests or golden vectors.
+ * This restatement is pinned against the *compiled reference itself*
+ * (oracle/_ref/libic_ref.so, built by `make -C oracle _ref` from the sources
+ * where they lie under /root/reference) by tests/test_oracle_vs_ref.py, and
+ * against the committed fixtures under tests/golden/ that were generated from
+ * that reference build by tests/golden/make_golden.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ */
+#ifndef IC_ORACLE_H_
+#define IC_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Block codecs (what is written), independent of the reference's class split. */
+enum { ICO_DXT1 = 0, ICO_DXT5 = 1, ICO_ETC1 = 2, ICO_PVRTC2 = 3 };
+
+/* Reference compressor classes and CompressedImage::Format (compressed_image.h:35-40). */
+enum { ICO_COMPRESSOR_DXTC = 0, ICO_COMPRESSOR_ETC = 1, ICO_COMPRESSOR_PVRTC = 2 };
+enum { ICO_RGB = 0, ICO_BGR = 1, ICO_RGBA = 2, ICO_BGRA = 3 };
+
+/* EtcCompressor::CompressionStrategy (public/etc_compressor.h:57-62). */
+enum { ICO_ETC_SPLIT_HORIZONTALLY = 0, ICO_ETC_SPLIT_VERTICALLY = 1,
+       ICO_ETC_SMALLER_ERROR = 2, ICO_ETC_HEURISTIC = 3 };
+
+/* ---- reference-shaped entry points (same argument meaning as Compressor::*) ---- */
+
+/* Compressor::ComputeCompressedDataSize (dxtc.cc:725-733, etc.cc:734-745, pvrtc.cc:631-634). */
+size_t ico_compute_compressed_data_size(int compressor, int format, uint32_t height, uint32_t width);
+
+/* Compressor::Compress into caller storage of exactly out_size bytes.
+ * Returns 1/0 like the reference's bool (0 also when out_size mismatches, the
+ * external-storage rule of compressor4x4_helper.cc:34-41). */
+int ico_compress(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                 uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out, size_t out_size);
+
+/* Compressor::CompressAndPad (helper.h:479-520). */
+int ico_compress_and_pad(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                         uint32_t padded_height, uint32_t padded_width, uint32_t padding_bytes_per_row,
+                         const uint8_t *buffer, uint8_t *out, size_t out_size);
+
+/* ---- generic block-grid encoder (covers the RGBA8->DXT1/ETC1 extension too) ----
+ * codec: ICO_*; src_components: 3 or 4 bytes per source pixel (alpha is ignored by
+ * DXT1/ETC1); swap_rb: source is B,G,R(,A); grid_* >= image dims select the
+ * CompressAndPad grid (pass the image dims for plain Compress).
+ * threads > 1 splits block rows into slabs (used only for the CPU baseline). */
+int ico_encode(int codec, int etc_strategy, int src_components, int swap_rb,
+               uint32_t height, uint32_t width, uint32_t grid_height, uint32_t grid_width,
+               uint32_t row_stride_bytes, const uint8_t *src, uint8_t *out, int threads);
+
+/* Bytes ico_encode writes for that grid. */
+size_t ico_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width);
+
+/* ---- decoders ("next" rows): DXT1/DXT5/ETC1 follow the reference
+ * (dxtc.cc:167-267, etc.cc:198-289, helper.h:218-262).  out has
+ * height * (width*comps + padding_bytes_per_row) bytes addressing, like the reference. */
+int ico_decode(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+               const uint8_t *blocks, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* IC_ORACLE_H_ */

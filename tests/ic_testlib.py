@@ -1,0 +1,239 @@
+"""Shared test plumbing: ctypes loaders for the oracle / compiled reference, and the
+deterministic synthetic-image generators of SURVEY.md 8(d).
+
+TEST INFRASTRUCTURE.  The product library (libic_amd.so) is loaded through the
+package loader in image-compression_amd/, never from here.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libic_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libic_ref.so")
+
+# block codecs (oracle/ic_oracle.h, include/ic_amd.h use the same numbering)
+DXT1, DXT5, ETC1, PVRTC2 = 0, 1, 2, 3
+# reference compressor classes / formats / ETC strategies
+DXTC, ETC, PVRTC = 0, 1, 2
+RGB, BGR, RGBA, BGRA = 0, 1, 2, 3
+SPLIT_H, SPLIT_V, SMALLER_ERROR, HEURISTIC = 0, 1, 2, 3
+
+u32, sz, vp, ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
+
+
+def comps_of(fmt):
+    return 3 if fmt in (RGB, BGR) else 4
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ORACLE_DIR, "ic_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "libic_oracle.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        L = ctypes.CDLL(build_oracle())
+        L.ico_compute_compressed_data_size.restype = sz
+        L.ico_compute_compressed_data_size.argtypes = [ci, ci, u32, u32]
+        L.ico_compress.restype = ci
+        L.ico_compress.argtypes = [ci, ci, ci, u32, u32, u32, vp, vp, sz]
+        L.ico_compress_and_pad.restype = ci
+        L.ico_compress_and_pad.argtypes = [ci, ci, ci, u32, u32, u32, u32, u32, vp, vp, sz]
+        L.ico_encode.restype = ci
+        L.ico_encode.argtypes = [ci, ci, ci, ci, u32, u32, u32, u32, u32, vp, vp, ci]
+        L.ico_encoded_size.restype = sz
+        L.ico_encoded_size.argtypes = [ci, u32, u32]
+        L.ico_decode.restype = ci
+        L.ico_decode.argtypes = [ci, ci, u32, u32, u32, vp, vp]
+        _oracle = L
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_ref = None
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = ctypes.CDLL(REF_SO)
+        L.ref_compressed_size.restype = sz
+        L.ref_compressed_size.argtypes = [ci, ci, u32, u32]
+        L.ref_compress.restype = ci
+        L.ref_compress.argtypes = [ci, ci, ci, u32, u32, u32, vp, vp, sz, vp]
+        L.ref_compress_owned.restype = ctypes.c_long
+        L.ref_compress_owned.argtypes = [ci, ci, ci, u32, u32, u32, vp, vp, sz]
+        L.ref_compress_and_pad.restype = ci
+        L.ref_compress_and_pad.argtypes = [ci, ci, ci, u32, u32, u32, u32, u32, vp, vp, sz, vp]
+        L.ref_decompress.restype = ctypes.c_long
+        L.ref_decompress.argtypes = [ci, ci, u32, u32, u32, u32, u32, vp, sz, vp, sz]
+        _ref = L
+    return _ref
+
+
+# ------------------------------------------------------------------ wrappers
+
+
+def oracle_size(compressor, fmt, h, w):
+    return oracle().ico_compute_compressed_data_size(compressor, fmt, h, w)
+
+
+def oracle_compress(compressor, fmt, img_bytes, h, w, pad=0, strategy=SMALLER_ERROR, out_size=None):
+    """Returns bytes, or None when the oracle returns false."""
+    n = oracle_size(compressor, fmt, h, w) if out_size is None else out_size
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.ascontiguousarray(img_bytes, dtype=np.uint8)
+    ok = oracle().ico_compress(compressor, strategy, fmt, h, w, pad, _ptr(src), _ptr(out), n)
+    return out[:n].tobytes() if ok else None
+
+
+def oracle_compress_and_pad(compressor, fmt, img_bytes, h, w, ph, pw, pad=0, strategy=SMALLER_ERROR):
+    n = oracle_size(compressor, fmt, max(h, ph), max(w, pw))
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.ascontiguousarray(img_bytes, dtype=np.uint8)
+    ok = oracle().ico_compress_and_pad(compressor, strategy, fmt, h, w, ph, pw, pad, _ptr(src), _ptr(out), n)
+    return out[:n].tobytes() if ok else None
+
+
+def oracle_encode(codec, src, h, w, comps, swap=0, strategy=SMALLER_ERROR, gh=None, gw=None, stride=None,
+                  threads=1):
+    gh = h if gh is None else gh
+    gw = w if gw is None else gw
+    stride = w * comps if stride is None else stride
+    n = oracle().ico_encoded_size(codec, max(gh, h), max(gw, w))
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    ok = oracle().ico_encode(codec, strategy, comps, swap, h, w, gh, gw, stride, _ptr(src), _ptr(out), threads)
+    return out[:n].tobytes() if ok else None
+
+
+def oracle_decode(codec, blocks, h, w, swap=0, pad=0):
+    comps = 4 if codec == DXT5 else 3
+    out = np.zeros(h * (w * comps + pad), np.uint8)
+    b = np.frombuffer(blocks, np.uint8)
+    ok = oracle().ico_decode(codec, swap, h, w, pad, _ptr(b), _ptr(out))
+    return out if ok else None
+
+
+def ref_size(compressor, fmt, h, w):
+    return ref().ref_compressed_size(compressor, fmt, h, w)
+
+
+def ref_compress(compressor, fmt, img_bytes, h, w, pad=0, strategy=SMALLER_ERROR, out_size=None):
+    n = ref_size(compressor, fmt, h, w) if out_size is None else out_size
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.ascontiguousarray(img_bytes, dtype=np.uint8)
+    ok = ref().ref_compress(compressor, strategy, fmt, h, w, pad, _ptr(src), _ptr(out), n, None)
+    return out[:n].tobytes() if ok else None
+
+
+def ref_compress_and_pad(compressor, fmt, img_bytes, h, w, ph, pw, pad=0, strategy=SMALLER_ERROR):
+    n = ref_size(compressor, fmt, max(h, ph), max(w, pw))
+    out = np.zeros(max(n, 1), np.uint8)
+    src = np.ascontiguousarray(img_bytes, dtype=np.uint8)
+    ok = ref().ref_compress_and_pad(compressor, strategy, fmt, h, w, ph, pw, pad, _ptr(src), _ptr(out), n, None)
+    return out[:n].tobytes() if ok else None
+
+
+def ref_decompress(compressor, fmt, blocks, h, w, pad=0):
+    comps = comps_of(fmt)
+    ch, cw = 4 * ((h + 3) // 4), 4 * ((w + 3) // 4)
+    cap = h * (w * comps + pad) + 64
+    out = np.zeros(cap, np.uint8)
+    b = np.frombuffer(blocks, np.uint8).copy()
+    n = ref().ref_decompress(compressor, fmt, h, w, ch, cw, pad, _ptr(b), b.size, _ptr(out), cap)
+    return None if n < 0 else out[:n]
+
+
+# --------------------------------------------------------- synthetic images
+# integer-only generators so host, device and every box agree.
+# numpy's PCG64 is deterministic across platforms for integers().
+
+SEED0 = 0x1234ABCD
+
+
+def _rng(seed_index):
+    return np.random.Generator(np.random.PCG64(SEED0 + seed_index))
+
+
+def s_noise(h, w, comps, index=0):
+    return _rng(index).integers(0, 256, size=(h, w, comps), dtype=np.uint8)
+
+
+def s_smooth(h, w, comps, index=0):
+    g = _rng(1000 + index)
+    y, x = np.mgrid[0:h, 0:w].astype(np.int64)
+    n = g.integers(0, 32, size=(h, w), dtype=np.int64)
+    img = np.empty((h, w, comps), np.uint8)
+    img[..., 0] = (255 * x // max(w, 1) + n) & 255
+    img[..., 1] = (255 * y // max(h, 1) + n) & 255
+    img[..., 2] = (255 * (x + y) // max(w + h, 1) + n) & 255
+    if comps == 4:
+        a = g.integers(0, 256, size=(h, w), dtype=np.int64)
+        keep = g.integers(0, 8, size=(h, w)) != 0
+        img[..., 3] = np.where(keep, 255, a)
+    return img
+
+
+def s_flat(h, w, comps, index=0):
+    g = _rng(2000 + index)
+    th, tw = (h + 15) // 16, (w + 15) // 16
+    tiles = g.integers(0, 256, size=(th, tw, comps), dtype=np.uint8)
+    img = np.repeat(np.repeat(tiles, 16, axis=0), 16, axis=1)[:h, :w].copy()
+    noisy = g.integers(0, 8, size=(th, tw)) == 0
+    mask = np.repeat(np.repeat(noisy, 16, axis=0), 16, axis=1)[:h, :w]
+    noise = g.integers(0, 256, size=(h, w, comps), dtype=np.uint8)
+    img[mask] = noise[mask]
+    return img
+
+
+def s_mixed(h, w, comps, index=0):
+    """Quadrant mix + special cases (near-constant, black, white, alpha 224..255, channel-zero areas)."""
+    g = _rng(3000 + index)
+    img = s_noise(h, w, comps, 50 + index)
+    h2, w2 = h // 2, w // 2
+    img[:h2, w2:] = s_smooth(h, w, comps, index)[:h2, w2:]
+    img[h2:, :w2] = s_flat(h, w, comps, index)[h2:, :w2]
+    q = img[h2:, w2:]
+    qh, qw = q.shape[:2]
+    base = g.integers(0, 256, size=(1, 1, comps), dtype=np.int64)
+    jitter = g.integers(-3, 4, size=(qh, qw, comps), dtype=np.int64)
+    q[...] = np.clip(base + jitter, 0, 255).astype(np.uint8)
+    if qh >= 8 and qw >= 24:
+        q[:4, :8] = 0
+        q[:4, 8:16] = 255
+        q[4:8, :8, 0] = 0  # a zero red channel (PVRTC max-index quirk)
+        if comps == 4:
+            q[4:8, 8:16, 3] = g.integers(224, 256, size=(4, 8), dtype=np.uint8)
+            q[:4, 16:24, 3] = 0
+    return img
+
+
+GENERATORS = {"noise": s_noise, "smooth": s_smooth, "flat": s_flat, "mixed": s_mixed}
+
+
+def with_row_padding(img, pad):
+    """(h, w, c) -> flat bytes with `pad` junk bytes after each row."""
+    h = img.shape[0]
+    flat = img.reshape(h, -1)
+    if pad == 0:
+        return np.ascontiguousarray(flat).reshape(-1)
+    junk = np.full((h, pad), 0xA5, np.uint8)
+    return np.ascontiguousarray(np.concatenate([flat, junk], axis=1)).reshape(-1)
