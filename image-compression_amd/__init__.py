@@ -1,0 +1,176 @@
+"""image-compression_amd: MI355X (gfx950) block-encode backend -- Python plumbing over the C ABI.
+
+This module only *binds* libic_amd.so (include/ic_amd.h) with ctypes and passes torch device
+pointers / streams through it.  All encoding happens in the hand-written HIP kernels inside the
+shared library; there is no Python or CPU implementation here, and importing fails loudly if the
+library has not been built (python __graft_entry__.py / make -C image-compression_amd).
+
+The directory name contains '-', so import it via `ic_amd_loader.load_package()` (repo root) or
+importlib; the package registers itself as `image_compression_amd`.
+"""
+import ctypes
+import os
+
+import torch  # must precede CDLL: libic_amd.so then binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libic_amd.so")
+
+# enums of include/ic_amd.h
+COMPRESSOR_DXTC, COMPRESSOR_ETC, COMPRESSOR_PVRTC = 0, 1, 2
+RGB, BGR, RGBA, BGRA = 0, 1, 2, 3
+ETC_SPLIT_HORIZONTALLY, ETC_SPLIT_VERTICALLY, ETC_SMALLER_ERROR, ETC_HEURISTIC = 0, 1, 2, 3
+DXT1, DXT5, ETC1, PVRTC2 = 0, 1, 2, 3
+OK, FALSE = 0, 1
+
+EXPORTS = [
+    "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
+    "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
+    "icamd_decode_device", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+]
+
+_u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
+_lib = None
+
+
+class BackendError(RuntimeError):
+    """The device path could not run (negative ICAMD_ERR_* status)."""
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libic_amd.so is not built (%s); run `python __graft_entry__.py` or "
+                              "`make -C image-compression_amd` -- there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.icamd_compute_compressed_data_size.restype = _sz
+        L.icamd_compute_compressed_data_size.argtypes = [_ci, _ci, _u32, _u32]
+        L.icamd_supports_format.restype = _ci
+        L.icamd_supports_format.argtypes = [_ci, _ci]
+        L.icamd_encoded_size.restype = _sz
+        L.icamd_encoded_size.argtypes = [_ci, _u32, _u32]
+        L.icamd_compress.restype = _ci
+        L.icamd_compress.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _vp, _sz]
+        L.icamd_compress_and_pad.restype = _ci
+        L.icamd_compress_and_pad.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _sz]
+        L.icamd_compress_device.restype = _ci
+        L.icamd_compress_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _vp, _sz, _vp]
+        L.icamd_compress_and_pad_device.restype = _ci
+        L.icamd_compress_and_pad_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp]
+        L.icamd_encode_device.restype = _ci
+        L.icamd_encode_device.argtypes = [_ci, _ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
+        L.icamd_decode_device.restype = _ci
+        L.icamd_decode_device.argtypes = [_ci, _ci, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
+        L.icamd_device_count.restype = _ci
+        L.icamd_last_error.restype = ctypes.c_char_p
+        L.icamd_version.restype = ctypes.c_char_p
+        L.icamd_kernel_name.restype = ctypes.c_char_p
+        L.icamd_kernel_name.argtypes = [_ci, _ci]
+        _lib = L
+    return _lib
+
+
+def _check(status, what):
+    if status < 0:
+        raise BackendError("%s failed with status %d: %s" % (what, status, lib().icamd_last_error().decode()))
+    return status == OK
+
+
+def compute_compressed_data_size(compressor, fmt, height, width):
+    return lib().icamd_compute_compressed_data_size(compressor, fmt, height, width)
+
+
+def encoded_size(codec, grid_height, grid_width):
+    return lib().icamd_encoded_size(codec, grid_height, grid_width)
+
+
+def kernel_name(codec, src_components):
+    return lib().icamd_kernel_name(codec, src_components).decode()
+
+
+def _stream_handle(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def encode_device(codec, src, height, width, src_components, *, swap_rb=False, etc_strategy=ETC_SMALLER_ERROR,
+                  grid_height=None, grid_width=None, row_stride_bytes=None, n_images=1,
+                  src_image_stride_bytes=None, out=None, stream=None):
+    """Launch the encode kernel on `src` (a torch.uint8 CUDA tensor, any shape, contiguous bytes).
+    Returns the output tensor [n_images, encoded_size] (device).  No synchronisation."""
+    assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+    gh = height if grid_height is None else max(grid_height, height)
+    gw = width if grid_width is None else max(grid_width, width)
+    stride = width * src_components if row_stride_bytes is None else row_stride_bytes
+    img_stride = height * stride if src_image_stride_bytes is None else src_image_stride_bytes
+    per = encoded_size(codec, gh, gw)
+    if out is None:
+        out = torch.empty((n_images, per), dtype=torch.uint8, device=src.device)
+    st = lib().icamd_encode_device(codec, etc_strategy, src_components, int(swap_rb), height, width, gh, gw, stride,
+                                   n_images, img_stride, per, ctypes.c_void_p(src.data_ptr()),
+                                   ctypes.c_void_p(out.data_ptr()), _stream_handle(stream))
+    if not _check(st, "icamd_encode_device"):
+        return None
+    return out
+
+
+def compress_device(compressor, fmt, src, height, width, *, padding_bytes_per_row=0,
+                    etc_strategy=ETC_SMALLER_ERROR, padded=None, out_size=None, stream=None):
+    """Compressor::Compress / CompressAndPad on a device-resident image; returns a device uint8 tensor or None
+    where the reference returns false."""
+    assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+    if padded is None:
+        n = compute_compressed_data_size(compressor, fmt, height, width) if out_size is None else out_size
+    else:
+        n = compute_compressed_data_size(compressor, fmt, max(height, padded[0]), max(width, padded[1])) \
+            if out_size is None else out_size
+    out = torch.empty((max(n, 1),), dtype=torch.uint8, device=src.device)
+    if padded is None:
+        st = lib().icamd_compress_device(compressor, etc_strategy, fmt, height, width, padding_bytes_per_row,
+                                         ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()), n,
+                                         _stream_handle(stream))
+    else:
+        st = lib().icamd_compress_and_pad_device(compressor, etc_strategy, fmt, height, width, padded[0], padded[1],
+                                                 padding_bytes_per_row, ctypes.c_void_p(src.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()), n, _stream_handle(stream))
+    if not _check(st, "icamd_compress_device"):
+        return None
+    return out[:n]
+
+
+def compress_host(compressor, fmt, buffer, height, width, *, padding_bytes_per_row=0,
+                  etc_strategy=ETC_SMALLER_ERROR, padded=None, out_size=None):
+    """The host-buffer drop-in (H2D + kernel + D2H inside the library).  `buffer`: bytes-like / numpy uint8.
+    Returns bytes, or None where the reference returns false."""
+    import numpy as np
+    src = np.ascontiguousarray(np.frombuffer(buffer, dtype=np.uint8) if not isinstance(buffer, np.ndarray) else buffer)
+    if padded is None:
+        n = compute_compressed_data_size(compressor, fmt, height, width) if out_size is None else out_size
+    else:
+        n = compute_compressed_data_size(compressor, fmt, max(height, padded[0]), max(width, padded[1])) \
+            if out_size is None else out_size
+    out = np.zeros(max(n, 1), np.uint8)
+    if padded is None:
+        st = lib().icamd_compress(compressor, etc_strategy, fmt, height, width, padding_bytes_per_row,
+                                  src.ctypes.data, out.ctypes.data, n)
+    else:
+        st = lib().icamd_compress_and_pad(compressor, etc_strategy, fmt, height, width, padded[0], padded[1],
+                                          padding_bytes_per_row, src.ctypes.data, out.ctypes.data, n)
+    if not _check(st, "icamd_compress"):
+        return None
+    return out[:n].tobytes()
+
+
+def decode_device(codec, blocks, height, width, *, swap_rb=False, padding_bytes_per_row=0, n_images=1, stream=None):
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+    comps = 4 if codec == DXT5 else 3
+    per_out = height * (width * comps + padding_bytes_per_row)
+    per_in = encoded_size(codec, height, width)
+    out = torch.zeros((n_images, per_out), dtype=torch.uint8, device=blocks.device)
+    st = lib().icamd_decode_device(codec, int(swap_rb), height, width, padding_bytes_per_row, n_images, per_in,
+                                   per_out, ctypes.c_void_p(blocks.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                   _stream_handle(stream))
+    if not _check(st, "icamd_decode_device"):
+        return None
+    return out

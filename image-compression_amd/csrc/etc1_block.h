@@ -1,0 +1,322 @@
+// etc1_block.h -- ETC1 block encoder (all four CompressionStrategy values), one block per lane.
+//
+// Bit-exact with EncodeEtc1Block (internal/etc_compressor.cc:545-586) and everything under it,
+// restructured for CDNA4 integer VALU.  The reference's hot loop (etc.cc:350-409) evaluates, per
+// sub-block pixel p and per candidate colour v = clamp(base + modifier), the squared distance
+//     |p - v|^2 = |p|^2 - (2 p.v - |v|^2)
+// and keeps the smallest (ties: lowest modifier index, then lowest codeword).  |p|^2 does not depend
+// on the candidate, so we maximise E = 2 p.v - |v|^2 instead:
+//   * p.v is ONE v_dot4_u32_u8 on the packed pixel / candidate dwords (clamping is already baked
+//     into v, so this is exact for every base colour, unlike a Sum(d)-based shortcut);
+//   * key = 4*E + (3-k) folds the tie rule into a signed max (v_lshl_add_u32 + v_max3_i32);
+//   * the 2-bit winner is shifted into an index word with v_alignbit_b32;
+//   * the 32 candidates of a sub-block are built with packed saturating 16-bit adds
+//     (v_pk_add_u16 / v_pk_sub_u16 clamp on 0xRR00BB00) + one v_perm_b32 each;
+//   * Sum|p|^2 over the 16 pixels is the same for both flips, so "error_lr <= error_tb"
+//     (etc.cc:583) is decided on Sum(E) alone.
+// ~3.8 k integer ops per block at kSmallerError: this codec is VALU-bound, not HBM-bound.
+#ifndef ICAMD_ETC1_BLOCK_H_
+#define ICAMD_ETC1_BLOCK_H_
+
+#include "dxt_block.h"  // Out8
+#include "ic_device.h"
+
+namespace icamd {
+
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t pk_addsat_u16(uint32_t a, uint32_t b) {
+  uint32_t lo = (a & 0xffffu) + (b & 0xffffu), hi = (a >> 16) + (b >> 16);
+  if (lo > 0xffffu) lo = 0xffffu;
+  if (hi > 0xffffu) hi = 0xffffu;
+  return hi << 16 | lo;
+}
+ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
+  uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+  return (ah > bh ? ah - bh : 0u) << 16 | (al > bl ? al - bl : 0u);
+}
+ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+#else
+typedef unsigned short icamd_us2 __attribute__((ext_vector_type(2)));
+// v_pk_add_u16 ... clamp / v_pk_sub_u16 ... clamp
+ICAMD_DEV uint32_t pk_addsat_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(icamd_us2, a),
+                                                                     __builtin_bit_cast(icamd_us2, b)));
+}
+ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(icamd_us2, a),
+                                                                     __builtin_bit_cast(icamd_us2, b)));
+}
+ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__popc(v); }
+#endif
+
+// ETC1 modifier table (OES_compressed_ETC1_RGB8_texture; etc.cc:101-110): row cw = {a, b, -a, -b}.
+// Packed as bytes so a per-lane codeword can look its row up with two v_bfe.
+constexpr uint32_t kEtcModA_lo = 2u | 5u << 8 | 9u << 16 | 13u << 24;
+constexpr uint32_t kEtcModA_hi = 18u | 24u << 8 | 33u << 16 | 47u << 24;
+constexpr uint32_t kEtcModB_lo = 8u | 17u << 8 | 29u << 16 | 42u << 24;
+constexpr uint32_t kEtcModB_hi = 60u | 80u << 8 | 106u << 16 | 183u << 24;
+constexpr int kEtcA[8] = { 2, 5, 9, 13, 18, 24, 33, 47 };
+constexpr int kEtcB[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
+
+// A sub-block's base colour in the two forms the candidate builder needs.
+struct EtcBase {
+  uint32_t rb_hi;  // 0xRR00BB00
+  uint32_t g_hi;   // 0x0000GG00
+};
+
+// Pixel j (0..7) of sub-block S under FLIP, enumerated in ascending ETC bit position 4x+y
+// (etc.cc:131-137) so that the index field order equals the output bit order.
+//   FLIP=0 (left|right halves, etc.cc:466-467): x in {2S, 2S+1}, y = 0..3  -> bit 8S + j
+//   FLIP=1 (top|bottom halves, etc.cc:464-465): y in {2S, 2S+1}, x = 0..3 -> bit 4(j>>1) + 2S + (j&1)
+template <int FLIP, int S>
+constexpr int sub_pixel(int j) {
+  return FLIP == 0 ? 4 * (j & 3) + (2 * S + (j >> 2))       // raster index 4y + x
+                   : 4 * (2 * S + (j & 1)) + (j >> 1);
+}
+
+// The 4 candidate colours of one codeword (modifiers +a, +b, -a, -b; etc.cc:121-125 clamps each
+// channel to 0..255) as packed R,G,B,0 dwords, and the per-candidate constant (3-k) - 4|v|^2.
+ICAMD_DEV void build_candidates(const EtcBase &base, uint32_t a, uint32_t b, uint32_t v[4], int32_t c[4]) {
+  const uint32_t a2 = a * 0x01000100u, b2 = b * 0x01000100u;  // modifier in the high byte of both halves
+  const uint32_t a1 = a << 8, b1 = b << 8;
+  // byte0 = R (rb byte 3), byte1 = G (g byte 1), byte2 = B (rb byte 1), byte3 = 0
+  const uint32_t sel = 0x0c050107u;
+  v[0] = perm(pk_addsat_u16(base.rb_hi, a2), pk_addsat_u16(base.g_hi, a1), sel);
+  v[1] = perm(pk_addsat_u16(base.rb_hi, b2), pk_addsat_u16(base.g_hi, b1), sel);
+  v[2] = perm(pk_subsat_u16(base.rb_hi, a2), pk_subsat_u16(base.g_hi, a1), sel);
+  v[3] = perm(pk_subsat_u16(base.rb_hi, b2), pk_subsat_u16(base.g_hi, b1), sel);
+  ICAMD_UNROLL
+  for (int k = 0; k < 4; ++k) c[k] = (3 - k) - 4 * (int32_t)udot4(v[k], v[k], 0u);
+}
+
+// ComputeCodewordError (etc.cc:350-385) for one codeword over the 8 pixels of a sub-block.
+// Returns 4 * Sum_p max_k E (the part of -error that depends on the codeword); *fields receives the
+// eight 2-bit values (3 - best_k) in bits 16..31, field j = pixel sub_pixel<FLIP,S>(j).
+template <int FLIP, int S>
+ICAMD_DEV int32_t eval_codeword(const uint32_t px[16], const uint32_t v[4], const int32_t c[4], uint32_t *fields) {
+  int32_t sum = 0;
+  uint32_t acc = 0;
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t p = px[sub_pixel<FLIP, S>(j)];
+    const int32_t k0 = (int32_t)(udot4(p, v[0], 0u) << 3) + c[0];
+    const int32_t k1 = (int32_t)(udot4(p, v[1], 0u) << 3) + c[1];
+    const int32_t k2 = (int32_t)(udot4(p, v[2], 0u) << 3) + c[2];
+    const int32_t k3 = (int32_t)(udot4(p, v[3], 0u) << 3) + c[3];
+    const int32_t m = imax(imax3(k0, k1, k2), k3);  // 4E + (3-k): best E, ties -> lowest k
+    sum += m;
+    acc = alignbit((uint32_t)m, acc, 2);
+  }
+  *fields = acc;
+  // remove the Sum(3-k) tie-break bits from the total: fields are pairs (lsb, msb) in bits 16..31
+  const uint32_t t = acc >> 16;
+  sum -= (int32_t)(popcount32(t & 0x5555u) + 2u * popcount32(t & 0xaaaau));
+  return sum;
+}
+
+struct EtcSubResult {
+  int32_t score;    // 4 * Sum_p max_k E for the chosen codeword (larger = smaller error)
+  uint32_t cw;      // chosen codeword 0..7
+  uint32_t fields;  // see eval_codeword
+};
+
+// FindBestCodeword (etc.cc:391-409): first codeword with the strictly smallest error.
+template <int FLIP, int S>
+ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const EtcBase &base) {
+  EtcSubResult r;
+  uint32_t v[4];
+  int32_t c[4];
+  build_candidates(base, (uint32_t)kEtcA[0], (uint32_t)kEtcB[0], v, c);
+  r.score = eval_codeword<FLIP, S>(px, v, c, &r.fields);
+  r.cw = 0;
+  ICAMD_UNROLL
+  for (int cw = 1; cw < 8; ++cw) {
+    uint32_t f;
+    build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
+    const int32_t s = eval_codeword<FLIP, S>(px, v, c, &f);
+    const bool better = s > r.score;
+    r.score = better ? s : r.score;
+    r.cw = better ? (uint32_t)cw : r.cw;
+    r.fields = better ? f : r.fields;
+  }
+  return r;
+}
+
+// FindCodewordHeuristic (etc.cc:415-455): codeword from the largest mean absolute deviation.
+template <int FLIP, int S>
+ICAMD_DEV EtcSubResult heuristic_codeword(const uint32_t px[16], const EtcBase &base, uint32_t br, uint32_t bg,
+                                          uint32_t bb) {
+  uint32_t sr = 0, sg = 0, sb = 0;
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t p = px[sub_pixel<FLIP, S>(j)];
+    sr = sad_u32(br, bfe(p, 0, 8), sr);
+    sg = sad_u32(bg, bfe(p, 8, 8), sg);
+    sb = sad_u32(bb, bfe(p, 16, 8), sb);
+  }
+  const uint32_t dev = umax3(sr >> 3, sg >> 3, sb >> 3);
+  const uint32_t cw = (dev > 144u) + (dev > 93u) + (dev > 70u) + (dev > 51u) + (dev > 35u) + (dev > 23u) + (dev > 12u);
+  const uint32_t sh = (cw & 3u) * 8u;
+  const uint32_t a = bfe(cw < 4u ? kEtcModA_lo : kEtcModA_hi, sh, 8);
+  const uint32_t b = bfe(cw < 4u ? kEtcModB_lo : kEtcModB_hi, sh, 8);
+  EtcSubResult r;
+  uint32_t v[4];
+  int32_t c[4];
+  build_candidates(base, a, b, v, c);
+  r.score = eval_codeword<FLIP, S>(px, v, c, &r.fields);
+  r.cw = cw;
+  return r;
+}
+
+struct EtcFlipResult {
+  int32_t score;          // sum of both sub-block scores
+  uint32_t hi;            // high word (flip, diff, codewords, colours), etc.cc:43-61
+  uint32_t f0, f1;        // index fields of sub-block 0 / 1
+};
+
+// FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
+template <int FLIP>
+ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t s0[3], const uint32_t s1[3], bool heuristic) {
+  // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
+  uint32_t q5a[3], q5b[3];
+  bool diff_mode = true;
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    q5a[ch] = s0[ch] >> 6;
+    q5b[ch] = s1[ch] >> 6;
+    const int32_t d = (int32_t)q5b[ch] - (int32_t)q5a[ch];
+    diff_mode = diff_mode && d >= -4 && d <= 3;
+  }
+  uint32_t hi = (uint32_t)FLIP;
+  uint32_t b0[3], b1[3];  // decoded base colours (what the decoder will reconstruct)
+  if (diff_mode) {
+    hi |= 2u;
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      const uint32_t d3 = (q5b[ch] - q5a[ch]) & 7u;  // 3-bit two's complement (bit_util.h:46-57)
+      hi |= q5a[ch] << (27 - 8 * ch) | d3 << (24 - 8 * ch);
+      b0[ch] = (q5a[ch] << 3) | (q5a[ch] >> 2);  // Extend5Bit, color_util.h:200-202
+      b1[ch] = (q5b[ch] << 3) | (q5b[ch] >> 2);
+    }
+  } else {
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      const uint32_t qa = s0[ch] >> 7, qb = s1[ch] >> 7;
+      hi |= qa << (28 - 8 * ch) | qb << (24 - 8 * ch);
+      b0[ch] = qa * 17u;  // Extend4Bit, color_util.h:193-195
+      b1[ch] = qb * 17u;
+    }
+  }
+  EtcBase e0 = { b0[0] << 24 | b0[2] << 8, b0[1] << 8 };
+  EtcBase e1 = { b1[0] << 24 | b1[2] << 8, b1[1] << 8 };
+  EtcSubResult r0, r1;
+  if (heuristic) {
+    r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
+    r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
+  } else {
+    r0 = search_codewords<FLIP, 0>(px, e0);
+    r1 = search_codewords<FLIP, 1>(px, e1);
+  }
+  EtcFlipResult out;
+  out.hi = hi | r0.cw << 5 | r1.cw << 2;
+  out.score = r0.score + r1.score;
+  out.f0 = r0.fields;
+  out.f1 = r1.fields;
+  return out;
+}
+
+// Turn the two sub-blocks' index fields into the low word (etc.cc:150-156, :539): bit 4x+y gets the
+// LSB of pixel (x,y)'s index, bit 16+4x+y the MSB.
+ICAMD_DEV uint32_t assemble_indices(uint32_t f0, uint32_t f1, bool flip) {
+  // fields hold (3 - k): invert; then z = [16 fields of sub0 | sub1] as pairs (lsb,msb)
+  const uint32_t z = ~((f0 >> 16) | (f1 & 0xffff0000u));
+  // split even (lsb) and odd (msb) bits: lsb plane -> low half, msb plane -> high half
+  uint32_t lsb = z & 0x55555555u, msb = (z >> 1) & 0x55555555u;
+  lsb = (lsb | lsb >> 1) & 0x33333333u; msb = (msb | msb >> 1) & 0x33333333u;
+  lsb = (lsb | lsb >> 2) & 0x0f0f0f0fu; msb = (msb | msb >> 2) & 0x0f0f0f0fu;
+  lsb = (lsb | lsb >> 4) & 0x00ff00ffu; msb = (msb | msb >> 4) & 0x00ff00ffu;
+  lsb = (lsb | lsb >> 8) & 0x0000ffffu; msb = (msb | msb >> 8) & 0x0000ffffu;
+  // now bit j of each plane = field j of sub-block 0 (j < 8) / sub-block 1 (j >= 8)
+  uint32_t planes = lsb | msb << 16;
+  if (flip) {
+    // FLIP=1: field j of sub-block S belongs at bit 4(j>>1) + 2S + (j&1): spread bit pairs to
+    // nibble starts, sub-block 1 shifted up by 2.
+    uint32_t s0 = planes & 0x00ff00ffu, s1 = (planes >> 8) & 0x00ff00ffu;
+    s0 = (s0 | s0 << 4) & 0x0f0f0f0fu; s1 = (s1 | s1 << 4) & 0x0f0f0f0fu;
+    s0 = (s0 | s0 << 2) & 0x33333333u; s1 = (s1 | s1 << 2) & 0x33333333u;
+    planes = s0 | s1 << 2;
+  }
+  return planes;
+}
+
+// EncodeEtc1Block (etc.cc:545-586).  Source channel order is always R,G,B (EtcCompressor accepts kRGB
+// only, etc.cc:751-754).  Returns the 8 output bytes: hi word then lo word, each big-endian (etc.cc:172-180).
+ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
+  // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
+  uint32_t qs[4][3];
+  ICAMD_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    qs[q][0] = qs[q][1] = qs[q][2] = 0;
+    ICAMD_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const int y = 2 * (q >> 1) + (i >> 1), x = 2 * (q & 1) + (i & 1);
+      const uint32_t p = px[4 * y + x];
+      qs[q][0] = udot4(p, 0x00000001u, qs[q][0]);
+      qs[q][1] = udot4(p, 0x00000100u, qs[q][1]);
+      qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
+    }
+  }
+  uint32_t left[3], right[3], top[3], bottom[3];
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    left[ch] = qs[0][ch] + qs[2][ch];
+    right[ch] = qs[1][ch] + qs[3][ch];
+    top[ch] = qs[0][ch] + qs[1][ch];
+    bottom[ch] = qs[2][ch] + qs[3][ch];
+  }
+  EtcFlipResult res;
+  bool flip;
+  if (strategy == 0u) {  // kSplitHorizontally: top|bottom only
+    res = encode_flip<1>(px, top, bottom, false);
+    flip = true;
+  } else if (strategy == 1u) {  // kSplitVertically: left|right only
+    res = encode_flip<0>(px, left, right, false);
+    flip = false;
+  } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574
+    // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
+    uint32_t e_lr = 0, e_tb = 0;
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      const uint32_t q3 = qs[3][ch] - bfe(px[15], 8 * ch, 8) + bfe(px[10], 8 * ch, 8);
+      const uint32_t l = (qs[0][ch] + qs[2][ch]) >> 3, r = (qs[1][ch] + q3) >> 3;
+      const uint32_t t = (qs[0][ch] + qs[1][ch]) >> 3, b = (qs[2][ch] + q3) >> 3;
+      const uint32_t dlr = sad_u32(l, r, 0u), dtb = sad_u32(t, b, 0u);
+      e_lr += dlr * dlr;
+      e_tb += dtb * dtb;
+    }
+    flip = !(e_lr > e_tb);
+    // both partitions are evaluated and the lane's choice selected, which keeps the wave convergent
+    const EtcFlipResult r0 = encode_flip<0>(px, left, right, true);
+    const EtcFlipResult r1 = encode_flip<1>(px, top, bottom, true);
+    res.hi = flip ? r1.hi : r0.hi;
+    res.f0 = flip ? r1.f0 : r0.f0;
+    res.f1 = flip ? r1.f1 : r0.f1;
+    res.score = 0;
+  } else {  // kSmallerError (and the reference's default: label)
+    const EtcFlipResult r0 = encode_flip<0>(px, left, right, false);
+    const EtcFlipResult r1 = encode_flip<1>(px, top, bottom, false);
+    // error_lr <= error_tb  <=>  score_lr >= score_tb  (same Sum|p|^2 on both sides)
+    flip = !(r0.score >= r1.score);
+    res.hi = flip ? r1.hi : r0.hi;
+    res.f0 = flip ? r1.f0 : r0.f0;
+    res.f1 = flip ? r1.f1 : r0.f1;
+    res.score = 0;
+  }
+  const uint32_t lo = assemble_indices(res.f0, res.f1, flip);
+  // big-endian words in memory = byte-reversed little-endian dwords
+  Out8 o = { perm(0u, res.hi, 0x00010203u), perm(0u, lo, 0x00010203u) };
+  return o;
+}
+
+}  // namespace icamd
+#endif  // ICAMD_ETC1_BLOCK_H_

@@ -1,0 +1,323 @@
+// ic_capi.hip -- implementation of the C ABI declared in include/ic_amd.h.
+//
+// Argument validation mirrors the reference's public wrappers (the bool they return
+// becomes ICAMD_OK / ICAMD_FALSE); everything else is geometry set-up and kernel
+// launches.  There is no CPU encode path in this library.
+#include "ic_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "ic_launch.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what, hipError_t e = hipSuccess) {
+  char buf[256];
+  if (e != hipSuccess)
+    std::snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+  else
+    std::snprintf(buf, sizeof buf, "%s", what);
+  g_last_error = buf;
+  return code;
+}
+
+#define ICAMD_HIP(call, what)                                   \
+  do {                                                          \
+    hipError_t e_ = (call);                                     \
+    if (e_ != hipSuccess) return fail(ICAMD_ERR_HIP, what, e_); \
+  } while (0)
+
+uint32_t num_blocks4(uint32_t n) { return (n + 3) / 4; }  // helper.h:86-88
+bool is_pow2(uint32_t x) { return x != 0 && !(x & (x - 1)); }
+int format_components(int format) {  // compressed_image.h:188-199
+  return (format == ICAMD_RGB || format == ICAMD_BGR) ? 3 : (format == ICAMD_RGBA || format == ICAMD_BGRA) ? 4 : 0;
+}
+bool format_swaps(int format) { return format == ICAMD_BGR || format == ICAMD_BGRA; }  // compressed_image.h:202-204
+
+uint32_t ilog2(uint32_t x) {
+  uint32_t l = 0;
+  while ((1u << l) < x) ++l;
+  return l;
+}
+
+// Per-thread device staging for the host-buffer entry points (grow-only).
+struct Staging {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  void *d_in = nullptr, *d_out = nullptr;
+  size_t cap_in = 0, cap_out = 0;
+  ~Staging() {
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int ensure(size_t in_bytes, size_t out_bytes) {
+    int dev = 0;
+    ICAMD_HIP(hipGetDevice(&dev), "hipGetDevice");
+    if (dev != device) {  // thread moved to another device: drop the old buffers
+      if (d_in) (void)hipFree(d_in);
+      if (d_out) (void)hipFree(d_out);
+      if (stream) (void)hipStreamDestroy(stream);
+      d_in = d_out = nullptr; cap_in = cap_out = 0; stream = nullptr;
+      device = dev;
+    }
+    if (!stream) ICAMD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (in_bytes > cap_in) {
+      if (d_in) (void)hipFree(d_in);
+      d_in = nullptr; cap_in = 0;
+      if (hipMalloc(&d_in, in_bytes) != hipSuccess) return fail(ICAMD_ERR_ALLOC, "hipMalloc(input staging)");
+      cap_in = in_bytes;
+    }
+    if (out_bytes > cap_out) {
+      if (d_out) (void)hipFree(d_out);
+      d_out = nullptr; cap_out = 0;
+      if (hipMalloc(&d_out, out_bytes) != hipSuccess) return fail(ICAMD_ERR_ALLOC, "hipMalloc(output staging)");
+      cap_out = out_bytes;
+    }
+    return ICAMD_OK;
+  }
+};
+thread_local Staging g_staging;
+
+int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(ICAMD_ERR_NO_DEVICE, "no HIP device available; this library has no CPU path", e);
+  return ICAMD_OK;
+}
+
+// What (compressor, format) encodes to; returns false when the reference's Compress would.
+bool resolve_codec(int compressor, int format, int *codec, int *comps, bool *swap) {
+  const int c = format_components(format);
+  if (c == 0) return false;
+  *comps = c;
+  *swap = format_swaps(format);
+  if (compressor == ICAMD_COMPRESSOR_DXTC) {  // dxtc.cc:741-749: 3 components -> DXT1, else DXT5
+    *codec = c == 3 ? ICAMD_DXT1 : ICAMD_DXT5;
+    return true;
+  }
+  if (compressor == ICAMD_COMPRESSOR_ETC) {  // etc.cc:751-754: kRGB only
+    if (format != ICAMD_RGB) return false;
+    *codec = ICAMD_ETC1;
+    return true;
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char *icamd_version(void) { return "image-compression_amd 0.1 (gfx950)"; }
+const char *icamd_last_error(void) { return g_last_error.c_str(); }
+
+int icamd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *icamd_kernel_name(int codec, int src_components) {
+  switch (codec) {
+    case ICAMD_DXT1: case ICAMD_DXT5: return icamd::dxt_kernel_name(codec, src_components);
+    case ICAMD_ETC1: return icamd::etc1_kernel_name(src_components);
+    case ICAMD_PVRTC2: return icamd::pvrtc2_kernel_name();
+  }
+  return "";
+}
+
+int icamd_supports_format(int compressor, int format) {
+  if (format_components(format) == 0) return 0;
+  if (compressor == ICAMD_COMPRESSOR_DXTC) return 1;                      // dxtc.cc:707-710
+  if (compressor == ICAMD_COMPRESSOR_ETC) return format == ICAMD_RGB;     // etc.cc:713-717
+  if (compressor == ICAMD_COMPRESSOR_PVRTC) return format == ICAMD_RGBA;  // pvrtc.cc:607-609
+  return 0;
+}
+
+size_t icamd_compute_compressed_data_size(int compressor, int format, uint32_t height, uint32_t width) {
+  if (compressor == ICAMD_COMPRESSOR_PVRTC) return (size_t)(width * height / 4);  // pvrtc.cc:631-634 (uint32 product)
+  if (height == 0 || width == 0) return 0;
+  const size_t blocks = (size_t)std::max(1u, num_blocks4(height)) * std::max(1u, num_blocks4(width));
+  if (compressor == ICAMD_COMPRESSOR_DXTC) return blocks * (format_components(format) == 3 ? 8u : 16u);  // dxtc.cc:276-280,725-733
+  if (compressor == ICAMD_COMPRESSOR_ETC) return format == ICAMD_RGB ? blocks * 8u : 0;                  // etc.cc:734-745
+  return 0;
+}
+
+size_t icamd_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width) {
+  if (codec == ICAMD_PVRTC2) return (size_t)grid_width * grid_height / 4;
+  return (size_t)num_blocks4(grid_height) * num_blocks4(grid_width) * (codec == ICAMD_DXT5 ? 16u : 8u);
+}
+
+int icamd_encode_device(int codec, int etc_strategy, int src_components, int swap_rb,
+                        uint32_t height, uint32_t width, uint32_t grid_height, uint32_t grid_width,
+                        uint32_t row_stride_bytes, uint32_t n_images,
+                        size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
+                        const void *d_src, void *d_dst, void *hip_stream) {
+  if (!d_src || !d_dst || height == 0 || width == 0) return ICAMD_FALSE;
+  if (src_components != 3 && src_components != 4) return fail(ICAMD_ERR_ARG, "src_components must be 3 or 4");
+  if (n_images == 0) return ICAMD_OK;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+
+  if (codec == ICAMD_PVRTC2) {
+    // preconditions of PvrtcCompressor::Compress, pvrtc.cc:636-650 (source always read as RGBA8888)
+    if (!is_pow2(width) || !is_pow2(height) || width != height || width % 8 || height % 4) return ICAMD_FALSE;
+    if (src_components != 4 || row_stride_bytes != width * 4u) return ICAMD_FALSE;
+    icamd::PvrtcParams P;
+    P.src = static_cast<const uint8_t *>(d_src);
+    P.dst = static_cast<uint8_t *>(d_dst);
+    P.src_image_stride = src_image_stride_bytes;
+    P.dst_image_stride = dst_image_stride_bytes;
+    P.size = width;
+    P.log2_size = ilog2(width);
+    P.n_images = n_images;
+    ICAMD_HIP(icamd::launch_pvrtc2(P, stream), "launch pvrtc2");
+    return ICAMD_OK;
+  }
+  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1) return fail(ICAMD_ERR_ARG, "unknown codec");
+  if (codec == ICAMD_DXT5 && src_components != 4) return fail(ICAMD_ERR_ARG, "DXT5 needs a 4-component source");
+  if (row_stride_bytes < width * (uint32_t)src_components) return fail(ICAMD_ERR_ARG, "row stride smaller than a row");
+
+  icamd::GridParams P;
+  P.src = static_cast<const uint8_t *>(d_src);
+  P.dst = static_cast<uint8_t *>(d_dst);
+  P.src_image_stride = src_image_stride_bytes;
+  P.dst_image_stride = dst_image_stride_bytes;
+  P.height = height;
+  P.width = width;
+  P.block_rows = num_blocks4(std::max(height, grid_height));  // helper.h:487-488,501-502
+  P.block_cols = num_blocks4(std::max(width, grid_width));
+  P.row_stride = row_stride_bytes;
+  const uint64_t bpi = (uint64_t)P.block_rows * P.block_cols;
+  const uint64_t total = bpi * n_images;
+  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  P.blocks_per_image = (uint32_t)bpi;
+  P.total_blocks = (uint32_t)total;
+  P.swap_rb = swap_rb ? 1u : 0u;
+  P.etc_strategy = (uint32_t)etc_strategy;
+  P.div_bpi = icamd::make_fastdiv(P.blocks_per_image);
+  P.div_cols = icamd::make_fastdiv(P.block_cols);
+  if (codec == ICAMD_ETC1)
+    ICAMD_HIP(icamd::launch_etc1(src_components, P, stream), "launch etc1");
+  else
+    ICAMD_HIP(icamd::launch_dxt(codec, src_components, P, stream), "launch dxt");
+  return ICAMD_OK;
+}
+
+int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
+                                  uint32_t height, uint32_t width,
+                                  uint32_t padded_height, uint32_t padded_width,
+                                  uint32_t padding_bytes_per_row,
+                                  const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) {
+  if (compressor == ICAMD_COMPRESSOR_PVRTC) return ICAMD_FALSE;  // pvrtc.cc:684-691
+  // dxtc.cc:799-818 / etc.cc:787-800
+  if (!d_buffer || !d_out || height == 0 || width == 0) return ICAMD_FALSE;
+  int codec, comps;
+  bool swap;
+  if (!resolve_codec(compressor, format, &codec, &comps, &swap)) return ICAMD_FALSE;
+  const uint32_t gh = std::max(height, padded_height), gw = std::max(width, padded_width);
+  const size_t need = icamd_encoded_size(codec, gh, gw);
+  if (out_size != need) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
+  return icamd_encode_device(codec, etc_strategy, comps, swap, height, width, gh, gw,
+                             width * (uint32_t)comps + padding_bytes_per_row, 1, 0, 0, d_buffer, d_out, hip_stream);
+}
+
+int icamd_compress_device(int compressor, int etc_strategy, int format,
+                          uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                          const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) {
+  if (compressor == ICAMD_COMPRESSOR_PVRTC) {
+    // pvrtc.cc:636-667.  `format` is deliberately not validated (neither does the reference).
+    if (!d_buffer || !d_out || height == 0 || width == 0) return ICAMD_FALSE;
+    if (!is_pow2(width) || !is_pow2(height) || width != height) return ICAMD_FALSE;
+    if (padding_bytes_per_row != 0) return ICAMD_FALSE;
+    if (width % 8 != 0 || height % 4 != 0) return ICAMD_FALSE;
+    if (out_size != (size_t)(width * height / 4)) return ICAMD_FALSE;
+    return icamd_encode_device(ICAMD_PVRTC2, 0, 4, 0, height, width, height, width, width * 4u, 1, 0, 0,
+                               d_buffer, d_out, hip_stream);
+  }
+  return icamd_compress_and_pad_device(compressor, etc_strategy, format, height, width, height, width,
+                                       padding_bytes_per_row, d_buffer, d_out, out_size, hip_stream);
+}
+
+static int compress_host_common(bool and_pad, int compressor, int etc_strategy, int format, uint32_t height,
+                                uint32_t width, uint32_t padded_height, uint32_t padded_width,
+                                uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out,
+                                size_t out_size) {
+  if (!buffer || !out || height == 0 || width == 0) return ICAMD_FALSE;
+  int comps = format_components(format);
+  if (compressor == ICAMD_COMPRESSOR_PVRTC) comps = 4;  // buffer is reinterpreted as RGBA8888, pvrtc.cc:664
+  if (comps == 0) return ICAMD_FALSE;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  const size_t in_bytes = (size_t)height * ((size_t)width * comps + padding_bytes_per_row);
+  rc = g_staging.ensure(in_bytes, std::max<size_t>(out_size, 1));
+  if (rc != ICAMD_OK) return rc;
+  hipStream_t s = g_staging.stream;
+  ICAMD_HIP(hipMemcpyAsync(g_staging.d_in, buffer, in_bytes, hipMemcpyHostToDevice, s), "H2D copy");
+  rc = and_pad ? icamd_compress_and_pad_device(compressor, etc_strategy, format, height, width, padded_height,
+                                               padded_width, padding_bytes_per_row, g_staging.d_in,
+                                               g_staging.d_out, out_size, s)
+               : icamd_compress_device(compressor, etc_strategy, format, height, width, padding_bytes_per_row,
+                                       g_staging.d_in, g_staging.d_out, out_size, s);
+  if (rc != ICAMD_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  ICAMD_HIP(hipMemcpyAsync(out, g_staging.d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
+  ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
+  return ICAMD_OK;
+}
+
+int icamd_compress(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                   uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out, size_t out_size) {
+  return compress_host_common(false, compressor, etc_strategy, format, height, width, height, width,
+                              padding_bytes_per_row, buffer, out, out_size);
+}
+
+int icamd_compress_and_pad(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                           uint32_t padded_height, uint32_t padded_width, uint32_t padding_bytes_per_row,
+                           const uint8_t *buffer, uint8_t *out, size_t out_size) {
+  return compress_host_common(true, compressor, etc_strategy, format, height, width, padded_height, padded_width,
+                              padding_bytes_per_row, buffer, out, out_size);
+}
+
+int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                        uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
+                        const void *d_blocks, void *d_pixels, void *hip_stream) {
+  if (!d_blocks || !d_pixels || height == 0 || width == 0) return ICAMD_FALSE;
+  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1) return ICAMD_FALSE;  // pvrtc.cc:669-672
+  if (n_images == 0) return ICAMD_OK;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  icamd::DecodeParams P;
+  P.blocks = static_cast<const uint8_t *>(d_blocks);
+  P.pixels = static_cast<uint8_t *>(d_pixels);
+  P.src_image_stride = src_image_stride_bytes;
+  P.dst_image_stride = dst_image_stride_bytes;
+  P.height = height;
+  P.width = width;
+  P.block_rows = num_blocks4(height);
+  P.block_cols = num_blocks4(width);
+  P.row_stride = width * (codec == ICAMD_DXT5 ? 4u : 3u) + padding_bytes_per_row;
+  const uint64_t bpi = (uint64_t)P.block_rows * P.block_cols, total = bpi * n_images;
+  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  P.blocks_per_image = (uint32_t)bpi;
+  P.total_blocks = (uint32_t)total;
+  P.swap_rb = swap_rb ? 1u : 0u;
+  P.div_bpi = icamd::make_fastdiv(P.blocks_per_image);
+  P.div_cols = icamd::make_fastdiv(P.block_cols);
+  ICAMD_HIP(icamd::launch_decode(codec, P, static_cast<hipStream_t>(hip_stream)), "launch decode");
+  return ICAMD_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

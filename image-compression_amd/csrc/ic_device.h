@@ -1,0 +1,203 @@
+// ic_device.h -- shared device-side helpers for the gfx950 block-encode kernels.
+//
+// Conventions used by every kernel in this directory:
+//  * one 4x4 block per lane (DXT/ETC); consecutive lanes own consecutive block
+//    columns, so a wave reads 64 x 16 B (RGBA8) or 64 x 12 B (RGB888) contiguous
+//    bytes per pixel row and writes 64 x 8/16 B contiguous output;
+//  * a pixel lives in one VGPR as a dword whose bytes are the source bytes in
+//    MEMORY order: byte0 = first channel (R, or B for kBGR*), byte1 = G,
+//    byte2 = third channel, byte3 = alpha (undefined for 3-byte sources --
+//    every consumer either masks it or multiplies it by a zero weight);
+//  * all arithmetic is 32-bit integer, like the reference (no floats).
+//
+// ICAMD_HOST_EMULATION (set ONLY by tests/host_emul, compiled with g++) swaps the
+// gfx950 instruction wrappers below for plain-C equivalents so the per-block
+// math in *_block.h can be unit-tested against the oracle without a GPU.  It is
+// never defined when libic_amd.so is built; the product has no CPU path.
+#ifndef ICAMD_IC_DEVICE_H_
+#define ICAMD_IC_DEVICE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(ICAMD_HOST_EMULATION)
+#define ICAMD_DEV static inline
+#define ICAMD_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define ICAMD_DEV __device__ __forceinline__
+#define ICAMD_UNROLL _Pragma("unroll")
+#endif
+
+namespace icamd {
+
+// Host-precomputed unsigned division n / d for n < 2^31 (block ids), d >= 1:
+// q = (umulhi(n, mul) + n) >> shift.
+struct FastDiv {
+  uint32_t mul, shift, d;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shift = s;
+  f.mul = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+
+// Geometry of one launch over a batch of equally shaped images.
+struct GridParams {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint64_t src_image_stride;  // bytes between images
+  uint64_t dst_image_stride;
+  uint32_t height, width;          // source image (pixels)
+  uint32_t block_rows, block_cols; // emitted block grid (>= image for CompressAndPad)
+  uint32_t row_stride;             // bytes between source rows
+  uint32_t blocks_per_image;
+  uint32_t total_blocks;           // blocks_per_image * n_images
+  uint32_t swap_rb;                // source is B,G,R(,A)
+  uint32_t etc_strategy;
+  FastDiv div_bpi, div_cols;
+};
+
+// ---- thin wrappers over the gfx950 instructions the kernels rely on ----
+#if defined(ICAMD_HOST_EMULATION)
+
+ICAMD_DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
+  for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xff) * ((b >> (8 * i)) & 0xff);
+  return c;
+}
+ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return (a > b ? a - b : b - a) + c; }
+ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
+  for (int i = 0; i < 4; ++i) {
+    int x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff;
+    c += (uint32_t)(x > y ? x - y : y - x);
+  }
+  return c;
+}
+ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
+}
+ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+  uint64_t v = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) {
+    uint32_t s = (sel >> (8 * i)) & 0xff;
+    uint32_t b = s <= 7 ? (uint32_t)((v >> (8 * s)) & 0xff) : (s == 0x0c ? 0u : 0xffu);
+    r |= b << (8 * i);
+  }
+  return r;
+}
+ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
+ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
+ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+#else  // gfx950
+
+ICAMD_DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+// v_dot4_u32_u8: a.b0*b.b0 + a.b1*b.b1 + a.b2*b.b2 + a.b3*b.b3 + c
+ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// v_sad_u32: |a - b| + c
+ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// v_sad_u8: sum over the 4 bytes of |a.b - b.b|, plus c
+ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
+// v_alignbit_b32: low 32 bits of ({hi,lo} >> sh)
+ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+// v_perm_b32: byte i of the result = byte sel.b[i] of the 8-byte value {hi,lo}
+// (selector 0..3 -> lo bytes, 4..7 -> hi bytes, 0x0c -> 0x00).
+ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return min(a, b); }
+ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return max(a, b); }
+ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return min(a, b); }
+ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return max(a, b); }
+
+#endif
+
+// The compiler folds these into v_min3/v_max3.
+ICAMD_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return umin(umin(a, b), c); }
+ICAMD_DEV uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return umax(umax(a, b), c); }
+ICAMD_DEV int32_t imax3(int32_t a, int32_t b, int32_t c) { return imax(imax(a, b), c); }
+
+ICAMD_DEV uint32_t fastdiv(uint32_t n, const FastDiv &f) { return (umulhi32(n, f.mul) + n) >> f.shift; }
+
+// Unaligned-tolerant vector loads (gfx950 global memory runs in unaligned-access
+// mode; the backend emits one global_load_dwordx3/x4 for these).
+struct __attribute__((packed, aligned(1))) U4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U3 { uint32_t x, y, z; };
+struct __attribute__((packed, aligned(1))) U2 { uint32_t x, y; };
+
+// Decompose a global block id into (image, block_row, block_col).
+ICAMD_DEV void locate_block(const GridParams &P, uint32_t k, uint32_t &img, uint32_t &brow, uint32_t &bcol) {
+  img = fastdiv(k, P.div_bpi);
+  uint32_t rem = k - img * P.blocks_per_image;
+  brow = fastdiv(rem, P.div_cols);
+  bcol = rem - brow * P.block_cols;
+}
+
+// Gather one 4x4 block (reference: internal/pixel4x4.h:44-67, pixel4x4.cc:23-59).
+// Interior blocks take 4 wide loads; edge blocks replicate the last row/column
+// (clamp-to-edge), byte by byte.
+template <int COMPS>
+ICAMD_DEV void load_block(const uint8_t *__restrict__ img, uint32_t h, uint32_t w, uint32_t stride,
+                          uint32_t row, uint32_t col, uint32_t px[16]) {
+  if (row + 4 <= h && col + 4 <= w) {
+    const uint8_t *p = img + (size_t)row * stride + (size_t)col * COMPS;
+    ICAMD_UNROLL
+    for (int y = 0; y < 4; ++y) {
+      if (COMPS == 4) {
+        U4 v = *reinterpret_cast<const U4 *>(p + (size_t)y * stride);
+        px[4 * y + 0] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w;
+      } else {
+        U3 v = *reinterpret_cast<const U3 *>(p + (size_t)y * stride);
+        px[4 * y + 0] = v.x;
+        px[4 * y + 1] = alignbit(v.y, v.x, 24);
+        px[4 * y + 2] = alignbit(v.z, v.y, 16);
+        px[4 * y + 3] = v.z >> 8;
+      }
+    }
+  } else {
+    ICAMD_UNROLL
+    for (int y = 0; y < 4; ++y) {
+      uint32_t sy = umin(row + y, h - 1);
+      ICAMD_UNROLL
+      for (int x = 0; x < 4; ++x) {
+        uint32_t sx = umin(col + x, w - 1);
+        const uint8_t *q = img + (size_t)sy * stride + (size_t)sx * COMPS;
+        uint32_t v = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16;
+        if (COMPS == 4) v |= (uint32_t)q[3] << 24;
+        px[4 * y + x] = v;
+      }
+    }
+  }
+}
+
+// Exact small-constant divisions on the operand ranges the encoders produce;
+// the ranges are checked exhaustively at compile time below.
+ICAMD_DEV uint32_t div3(uint32_t x) { return (x * 683u) >> 11; }   // x <= 765  = 3*255
+ICAMD_DEV uint32_t div5(uint32_t x) { return (x * 3277u) >> 14; }  // x <= 1275 = 5*255
+ICAMD_DEV uint32_t div7(uint32_t x) { return (x * 9363u) >> 16; }  // x <= 1785 = 7*255
+
+namespace detail {
+constexpr bool check_div(uint32_t d, uint32_t mul, uint32_t sh, uint32_t max) {
+  for (uint32_t x = 0; x <= max; ++x)
+    if (((x * mul) >> sh) != x / d) return false;
+  return true;
+}
+static_assert(check_div(3, 683, 11, 765), "div3 magic");
+static_assert(check_div(5, 3277, 14, 1275), "div5 magic");
+static_assert(check_div(7, 9363, 16, 1785), "div7 magic");
+}  // namespace detail
+
+}  // namespace icamd
+#endif  // ICAMD_IC_DEVICE_H_

@@ -1,0 +1,128 @@
+/* ic_amd.h -- C ABI of the MI355X (gfx950) texture block-encode backend.
+ *
+ * Drop-in boundary for the per-4x4-block encode path of google/image-compression:
+ * these entry points are what a C FFI for `image_codec_compression::Compressor`
+ * (reference image_compression/public/compressor.h:48-138) binds for the hot path,
+ * and what our own C++ `DxtcCompressor / EtcCompressor / PvrtcCompressor` classes
+ * (image-compression_amd/cxx/) call.  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  INTEGRATION.md shows the reference-side binding.
+ *
+ * There is NO CPU fallback behind this ABI: every encode entry point runs the
+ * hand-written HIP kernels on the current HIP device, and returns a negative
+ * ICAMD_ERR_* (never silently a host result) when no device / kernel is available.
+ */
+#ifndef IC_AMD_H_
+#define IC_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enumerations (values match the reference's enums so they can be passed through) ---- */
+
+/* Which reference Compressor subclass is being replaced. */
+enum { ICAMD_COMPRESSOR_DXTC = 0,   /* public/dxtc_compressor.h:52-83  */
+       ICAMD_COMPRESSOR_ETC = 1,    /* public/etc_compressor.h:53-109  */
+       ICAMD_COMPRESSOR_PVRTC = 2 };/* public/pvrtc_compressor.h:71-104 */
+
+/* CompressedImage::Format, public/compressed_image.h:35-40. */
+enum { ICAMD_RGB = 0, ICAMD_BGR = 1, ICAMD_RGBA = 2, ICAMD_BGRA = 3 };
+
+/* EtcCompressor::CompressionStrategy, public/etc_compressor.h:57-62. */
+enum { ICAMD_ETC_SPLIT_HORIZONTALLY = 0, ICAMD_ETC_SPLIT_VERTICALLY = 1,
+       ICAMD_ETC_SMALLER_ERROR = 2, ICAMD_ETC_HEURISTIC = 3 };
+
+/* Block codec actually written (the reference derives it from compressor + format,
+ * internal/dxtc_compressor.cc:741-749). */
+enum { ICAMD_DXT1 = 0, ICAMD_DXT5 = 1, ICAMD_ETC1 = 2, ICAMD_PVRTC2 = 3 };
+
+/* Status codes.  0 = the reference's `true`; 1 = the reference's `false` (argument
+ * validation, unsupported format, external-storage size mismatch); < 0 = the device
+ * path could not run -- callers must treat that as a hard error. */
+enum { ICAMD_OK = 0, ICAMD_FALSE = 1,
+       ICAMD_ERR_NO_DEVICE = -1, ICAMD_ERR_HIP = -2, ICAMD_ERR_ALLOC = -3, ICAMD_ERR_ARG = -4 };
+
+/* ---- size / capability queries (host only, no device needed) ---- */
+
+/* Compressor::ComputeCompressedDataSize -- compressor.h:68-69; semantics of
+ * dxtc_compressor.cc:725-733, etc_compressor.cc:734-745, pvrtc_compressor.cc:631-634. */
+size_t icamd_compute_compressed_data_size(int compressor, int format, uint32_t height, uint32_t width);
+
+/* Compressor::SupportsFormat -- compressor.h:54; dxtc.cc:700-703 (all four),
+ * etc.cc:713-717 (kRGB only), pvrtc.cc:607-609 (kRGBA only). */
+int icamd_supports_format(int compressor, int format);
+
+/* Bytes written by icamd_encode_device for one image of that block grid. */
+size_t icamd_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width);
+
+/* ---- the hot path, host buffers: exact drop-in for Compressor::Compress ----
+ * compressor.h:77-80 (note (height, width) order).  `buffer` is `height` rows of
+ * width*components + padding_bytes_per_row bytes of host memory; `out` is caller storage
+ * of exactly out_size == icamd_compute_compressed_data_size(...) bytes (the reference's
+ * external-storage contract, internal/compressor4x4_helper.cc:34-41).
+ * Does H2D, kernel, D2H on an internal per-thread stream and returns when `out` is filled. */
+int icamd_compress(int compressor, int etc_strategy, int format,
+                   uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                   const uint8_t *buffer, uint8_t *out, size_t out_size);
+
+/* Compressor::CompressAndPad -- compressor.h:114-119; helper.h:479-520.
+ * PVRTC returns ICAMD_FALSE like pvrtc_compressor.cc:684-691. */
+int icamd_compress_and_pad(int compressor, int etc_strategy, int format,
+                           uint32_t height, uint32_t width,
+                           uint32_t padded_height, uint32_t padded_width,
+                           uint32_t padding_bytes_per_row,
+                           const uint8_t *buffer, uint8_t *out, size_t out_size);
+
+/* ---- the hot path, device-resident (the roofline entry points) ----
+ * Same contracts, but `d_buffer` / `d_out` are device pointers on the current HIP
+ * device and the work is enqueued on `hip_stream` (a hipStream_t, NULL = default
+ * stream) without synchronising. */
+int icamd_compress_device(int compressor, int etc_strategy, int format,
+                          uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                          const void *d_buffer, void *d_out, size_t out_size, void *hip_stream);
+
+int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
+                                  uint32_t height, uint32_t width,
+                                  uint32_t padded_height, uint32_t padded_width,
+                                  uint32_t padding_bytes_per_row,
+                                  const void *d_buffer, void *d_out, size_t out_size, void *hip_stream);
+
+/* Generic block-grid encoder over a batch of equally-shaped images (one launch).
+ *   codec            ICAMD_DXT1 / DXT5 / ETC1 / PVRTC2
+ *   src_components   3 or 4 bytes per source pixel.  4 with DXT1/ETC1 is the
+ *                    "RGBA8, alpha ignored" extension named by BASELINE.json; its result
+ *                    is defined as the reference's output for the alpha-stripped image.
+ *   swap_rb          source is B,G,R(,A) (NeedsRedAndBlueSwapped, compressed_image.h:202-204)
+ *   grid_height/width  >= height/width: block grid to emit (CompressAndPad); pass the
+ *                    image dims for plain Compress.
+ *   row_stride_bytes distance between source rows; *_image_stride_bytes between images.
+ * Image i is read at d_src + i*src_image_stride_bytes and its blocks written at
+ * d_dst + i*dst_image_stride_bytes (row-major blocks; PVRTC: Z-order, pvrtc.cc:551-580). */
+int icamd_encode_device(int codec, int etc_strategy, int src_components, int swap_rb,
+                        uint32_t height, uint32_t width, uint32_t grid_height, uint32_t grid_width,
+                        uint32_t row_stride_bytes, uint32_t n_images,
+                        size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
+                        const void *d_src, void *d_dst, void *hip_stream);
+
+/* ---- "next" row 8f.1: block decoders on device (Compressor::Decompress, compressor.h:85-86;
+ * helper.h:218-262, dxtc.cc:167-267, etc.cc:198-289).  Writes height rows of
+ * width*comps + padding_bytes_per_row bytes (comps = 4 for DXT5, else 3). */
+int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
+                        uint32_t padding_bytes_per_row, uint32_t n_images,
+                        size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
+                        const void *d_blocks, void *d_pixels, void *hip_stream);
+
+/* ---- runtime ---- */
+int icamd_device_count(void);             /* HIP devices visible; 0 if none */
+const char *icamd_last_error(void);       /* thread-local message for the last negative status */
+const char *icamd_version(void);
+/* Name of the __global__ kernel a given configuration launches (for matching rocprofv3 rows). */
+const char *icamd_kernel_name(int codec, int src_components);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IC_AMD_H_ */

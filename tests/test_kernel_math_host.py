@@ -1,0 +1,83 @@
+"""CPU tier: the per-block kernel math (image-compression_amd/csrc/*_block.h) compiled for the host with
+the gfx950 instruction wrappers emulated (tests/host_emul), checked against the oracle.  This is NOT a
+product path -- it only lets kernel-logic regressions show up without a GPU; the real parity tests are
+tests/test_gpu_parity.py (-m gpu) which run the HIP kernels through the C ABI."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ic_testlib as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, "host_emul")
+CSRC = os.path.join(T.ROOT, "image-compression_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL_DIR, "libic_emul.so")
+    srcs = [os.path.join(EMUL_DIR, "emul.cc")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DICAMD_HOST_EMULATION",
+                               "-I" + CSRC, "-o", so, os.path.join(EMUL_DIR, "emul.cc")])
+    L = ctypes.CDLL(so)
+    L.emul_encode.restype = ctypes.c_int
+    L.emul_encode.argtypes = [T.ci, T.ci, T.ci, T.ci, T.u32, T.u32, T.u32, T.u32, T.u32, T.vp, T.vp]
+    return L
+
+
+def emul_encode(L, codec, src, h, w, comps, swap=0, strategy=2, gh=None, gw=None, stride=None):
+    gh = h if gh is None else gh
+    gw = w if gw is None else gw
+    stride = w * comps if stride is None else stride
+    n = T.oracle().ico_encoded_size(codec, max(gh, h), max(gw, w))
+    out = np.zeros(n, np.uint8)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    # over-allocate: interior loads read 16 B per row even for the last pixel
+    buf = np.concatenate([src.reshape(-1), np.zeros(64, np.uint8)])
+    ok = L.emul_encode(codec, strategy, comps, swap, h, w, gh, gw, stride, buf.ctypes.data, out.ctypes.data)
+    return out.tobytes() if ok else None
+
+
+CASES = [(T.DXT1, 3, 0, 2), (T.DXT1, 3, 1, 2), (T.DXT1, 4, 0, 2), (T.DXT1, 4, 1, 2), (T.DXT5, 4, 0, 2),
+         (T.DXT5, 4, 1, 2), (T.ETC1, 3, 0, 0), (T.ETC1, 3, 0, 1), (T.ETC1, 3, 0, 2), (T.ETC1, 3, 0, 3),
+         (T.ETC1, 4, 0, 2), (T.ETC1, 4, 0, 3)]
+
+
+@pytest.mark.parametrize("codec,comps,swap,strategy", CASES)
+@pytest.mark.parametrize("gen", ["noise", "smooth", "flat", "mixed"])
+def test_block_math_matches_oracle(emul, codec, comps, swap, strategy, gen):
+    for (h, w, pad) in [(64, 64, 0), (61, 59, 3), (5, 3, 0), (1, 1, 0)]:
+        img = T.GENERATORS[gen](h, w, comps, index=h * 7 + w)
+        src = T.with_row_padding(img, pad)
+        stride = w * comps + pad
+        want = T.oracle_encode(codec, src, h, w, comps, swap, strategy, stride=stride)
+        got = emul_encode(emul, codec, src, h, w, comps, swap, strategy, stride=stride)
+        assert got == want, (gen, h, w, pad)
+
+
+@pytest.mark.parametrize("codec,comps,swap,strategy", CASES)
+def test_block_math_pad_grid(emul, codec, comps, swap, strategy):
+    img = T.s_mixed(30, 30, comps, index=60)
+    src = T.with_row_padding(img, 8)
+    want = T.oracle_encode(codec, src, 30, 30, comps, swap, strategy, gh=40, gw=48, stride=30 * comps + 8)
+    got = emul_encode(emul, codec, src, 30, 30, comps, swap, strategy, gh=40, gw=48, stride=30 * comps + 8)
+    assert got == want
+
+
+def test_block_math_random_blocks(emul):
+    g = np.random.Generator(np.random.PCG64(7))
+    n = 1 << 14
+    for codec, comps, swap, strategy in CASES:
+        strip = g.integers(0, 256, size=(4, 4 * n, comps), dtype=np.uint8)
+        base = g.integers(0, 256, size=(1, n // 2, 1, comps), dtype=np.int64)
+        jit = g.integers(-3, 4, size=(4, n // 2, 4, comps), dtype=np.int64)
+        strip[:, : 2 * n] = np.clip(base + jit, 0, 255).astype(np.uint8).reshape(4, 2 * n, comps)
+        # extremes: make some blocks saturate the ETC clamps
+        strip[:, 2 * n: 2 * n + 256] = g.choice(np.array([0, 1, 254, 255], np.uint8), size=(4, 256, comps))
+        want = T.oracle_encode(codec, strip, 4, 4 * n, comps, swap, strategy)
+        got = emul_encode(emul, codec, strip, 4, 4 * n, comps, swap, strategy)
+        assert got == want, (codec, comps, swap, strategy)
