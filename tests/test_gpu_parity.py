@@ -159,3 +159,48 @@ def test_etc1_batch_1024(pkg):
     for i in (0, n - 1):
         assert out[i].cpu().numpy().tobytes() == T.oracle_encode(T.ETC1, imgs[i], h, w, 3, threads=8)
     # golden: 1024^2 noise/smooth hashes are in hashes.json and were checked by test_golden_hashes_device_api
+
+
+# ---- PVRTC1 2bpp (fused tile kernel with LDS halo)
+
+def test_pvrtc_matches_oracle(pkg):
+    for n in (8, 16, 32, 64, 128, 256, 512):
+        for gen in ("noise", "smooth", "flat", "mixed"):
+            img = T.GENERATORS[gen](n, n, 4, index=n)
+            out = pkg.encode_device(T.PVRTC2, _dev(img), n, n, 4)
+            assert _host(out) == T.oracle_encode(T.PVRTC2, img, n, n, 4), (n, gen)
+    img = np.zeros((32, 32, 4), np.uint8)  # never-updated maxima refer to image pixel 0 (pvrtc.cc:268-269)
+    img[0, 0] = (250, 3, 7, 255)
+    img[8:, :, 1] = 200
+    img[:, 16:, 3] = 255
+    assert _host(pkg.encode_device(T.PVRTC2, _dev(img), 32, 32, 4)) == T.oracle_encode(T.PVRTC2, img, 32, 32, 4)
+
+
+def test_pvrtc_batch_and_full_size_4096(pkg):
+    import torch
+    imgs = np.stack([T.s_mixed(128, 128, 4, index=i) for i in range(3)])
+    out = pkg.encode_device(T.PVRTC2, _dev(imgs), 128, 128, 4, n_images=3)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert out[i].cpu().numpy().tobytes() == T.oracle_encode(T.PVRTC2, imgs[i], 128, 128, 4)
+    n = 4096  # BASELINE.json config 5
+    img = T.s_smooth(n, n, 4, index=6)
+    img[:1024, :1024] = T.s_noise(1024, 1024, 4, index=6)
+    img[1024:2048, :1024] = T.s_flat(1024, 1024, 4, index=6)
+    got = _host(pkg.encode_device(T.PVRTC2, _dev(img), n, n, 4))
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(T.oracle_encode(T.PVRTC2, img, n, n, 4)).hexdigest()
+    # toroidal property: rolling the image by whole tiles permutes blocks but keeps each block's bytes
+    # (every block sees the same wrapped neighbourhood) as long as image pixel 0 stays the same colour
+    small = T.s_noise(256, 256, 4, index=8)
+    small[..., :3] |= 1  # no all-zero channel, so pixel 0 is never consulted
+    a = np.frombuffer(_host(pkg.encode_device(T.PVRTC2, _dev(small), 256, 256, 4)), np.uint8).reshape(-1, 8)
+    rolled = np.ascontiguousarray(np.roll(small, (64, 128), axis=(0, 1)))
+    b = np.frombuffer(_host(pkg.encode_device(T.PVRTC2, _dev(rolled), 256, 256, 4)), np.uint8).reshape(-1, 8)
+
+    def z(bx, by):
+        r = 0
+        for j in range(16):
+            r |= ((bx >> j) & 1) << (2 * j + 1) | ((by >> j) & 1) << (2 * j)
+        return r
+    for (bx, by) in [(0, 0), (5, 7), (31, 63), (16, 16), (17, 3)]:
+        assert a[z(bx, by)].tobytes() == b[z((bx + 16) % 32, (by + 16) % 64)].tobytes()

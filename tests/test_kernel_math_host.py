@@ -81,3 +81,17 @@ def test_block_math_random_blocks(emul):
         want = T.oracle_encode(codec, strip, 4, 4 * n, comps, swap, strategy)
         got = emul_encode(emul, codec, strip, 4, 4 * n, comps, swap, strategy)
         assert got == want, (codec, comps, swap, strategy)
+
+
+def test_pvrtc_math_matches_oracle(emul):
+    for n in (8, 16, 32, 64, 128):
+        for gen in ("noise", "smooth", "flat", "mixed"):
+            img = T.GENERATORS[gen](n, n, 4, index=n)
+            want = T.oracle_encode(T.PVRTC2, img, n, n, 4)
+            got = emul_encode(emul, T.PVRTC2, img, n, n, 4)
+            assert got == want, (n, gen)
+    img = np.zeros((32, 32, 4), np.uint8)  # never-updated maxima refer to image pixel 0
+    img[0, 0] = (250, 3, 7, 255)
+    img[8:, :, 1] = 200
+    img[:, 16:, 3] = 255
+    assert emul_encode(emul, T.PVRTC2, img, 32, 32, 4) == T.oracle_encode(T.PVRTC2, img, 32, 32, 4)
