@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Summarises gpurun_out/prof/<workload>/ (written on the GPU box by scripts/gpu_profile.sh) into
+profiles/<round>_<workload>_{kernel_stats.csv,summary.json} and profiles/traffic.json.
+
+HBM traffic = FETCH_SIZE * 2 + WRITE_SIZE (KiB -> bytes): on gfx950 this rocprofv3 reports exactly half
+of the bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, section HBM), so the read side is
+doubled; WRITE_SIZE is taken as reported.  FETCH_SIZE and WRITE_SIZE come from separate --pmc passes.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+
+
+def counters(path):
+    agg = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        if r["Kernel_Name"].startswith("icamd_"):
+            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    os.makedirs(DST, exist_ok=True)
+    tpath = os.path.join(DST, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    for wl in sorted(os.listdir(SRC)):
+        d = os.path.join(SRC, wl)
+        if not os.path.isdir(d):
+            continue
+        stats_csv = os.path.join(d, "trace", wl + "_kernel_stats.csv")
+        if not os.path.exists(stats_csv):
+            continue
+        rows = list(csv.DictReader(open(stats_csv)))
+        out_csv = os.path.join(DST, "%s_%s_kernel_stats.csv" % (rnd, wl))
+        with open(out_csv, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+        summary = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 "
+                   "--workload %s --no-cpu-baseline --no-verify" % wl, "kernels": {}}
+        for r in rows:
+            if r["Name"].startswith("icamd_"):
+                summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+        fetch = counters(os.path.join(d, "pmc_fetch", wl + "_counter_collection.csv"))
+        write = counters(os.path.join(d, "pmc_write", wl + "_counter_collection.csv"))
+        sq = counters(os.path.join(d, "pmc_sq", wl + "_counter_collection.csv"))
+        for (k, c), v in list(fetch.items()) + list(write.items()) + list(sq.items()):
+            summary["kernels"].setdefault(k, {})[c] = v
+        for k, e in summary["kernels"].items():
+            if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2  # gfx950 half-count correction
+                e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
+                e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+                traffic[wl] = int(e["hbm_bytes_per_launch"])
+            if "SQ_INSTS_VALU" in e and "SQ_WAVES" in e:
+                e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+        bj = os.path.join(SRC, wl + ".bench.json")
+        if os.path.exists(bj):
+            try:
+                summary["bench_line_under_profiler"] = json.load(open(bj))
+            except Exception:
+                pass
+        with open(os.path.join(DST, "%s_%s_summary.json" % (rnd, wl)), "w") as f:
+            json.dump(summary, f, indent=1, sort_keys=True)
+        print(wl, json.dumps({k: {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in e.items()}
+                              for k, e in summary["kernels"].items()})[:600])
+    with open(tpath, "w") as f:
+        json.dump(traffic, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
