@@ -26,7 +26,7 @@ OK, FALSE = 0, 1
 EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
-    "icamd_decode_device", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_decode_device", "icamd_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -62,6 +62,8 @@ def lib():
         L.icamd_encode_device.argtypes = [_ci, _ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
         L.icamd_decode_device.restype = _ci
         L.icamd_decode_device.argtypes = [_ci, _ci, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
+        L.icamd_decompress.restype = _ci
+        L.icamd_decompress.argtypes = [_ci, _ci, _u32, _u32, _u32, _vp, _sz, _vp, _sz]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p

@@ -1,6 +1,83 @@
-// decode_kernels.hip -- DXT1/DXT5/ETC1 block decoders (placeholder).
+// decode_kernels.hip -- DXT1 / DXT5 / ETC1 decode kernels for gfx950 ("next" row 8f.1): one block per
+// lane, 8/16-byte coalesced block loads, 12/16-byte row-segment stores (Compressor4x4Helper::Decompress,
+// internal/compressor4x4_helper.h:218-262: blocks past the image edge are clipped).
+#include "decode_block.h"
 #include "ic_launch.h"
+#include "ic_amd.h"
 
 namespace icamd {
-hipError_t launch_decode(int, const DecodeParams &, hipStream_t) { return hipErrorNotSupported; }
+
+template <int CODEC>
+__device__ __forceinline__ void decode_one(const DecodeParams &P, uint32_t k) {
+  constexpr int COMPS = CODEC == ICAMD_DXT5 ? 4 : 3;
+  const uint32_t img = fastdiv(k, P.div_bpi);
+  const uint32_t rem = k - img * P.blocks_per_image;
+  const uint32_t brow = fastdiv(rem, P.div_cols), bcol = rem - brow * P.block_cols;
+  const uint8_t *src = P.blocks + (size_t)img * P.src_image_stride + (size_t)rem * (CODEC == ICAMD_DXT5 ? 16 : 8);
+  uint32_t px[16];
+  const bool swap = P.swap_rb != 0;
+  if (CODEC == ICAMD_DXT5) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(src);
+    decode_dxt_colors(w.z, w.w, swap, true, px);
+    decode_dxt5_alpha(w.x, w.y, px);
+  } else {
+    const uint2 w = *reinterpret_cast<const uint2 *>(src);
+    if (CODEC == ICAMD_DXT1) decode_dxt_colors(w.x, w.y, swap, false, px);
+    else decode_etc1(w.x, w.y, px);
+  }
+  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride;
+  const uint32_t row = brow * 4, col = bcol * 4;
+  if (row + 4 <= P.height && col + 4 <= P.width) {
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      uint8_t *q = dst + (size_t)(row + y) * P.row_stride + (size_t)col * COMPS;
+      if (COMPS == 4) {
+        U4 v = { px[4 * y], px[4 * y + 1], px[4 * y + 2], px[4 * y + 3] };
+        *reinterpret_cast<U4 *>(q) = v;
+      } else {
+        const uint32_t a = px[4 * y] & 0xffffffu, b = px[4 * y + 1] & 0xffffffu, c = px[4 * y + 2] & 0xffffffu,
+                       d = px[4 * y + 3] & 0xffffffu;
+        U3 v = { a | b << 24, b >> 8 | c << 16, c >> 16 | d << 8 };
+        *reinterpret_cast<U3 *>(q) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (row + y < P.height && col + x < P.width) {
+          uint8_t *q = dst + (size_t)(row + y) * P.row_stride + (size_t)(col + x) * COMPS;
+          const uint32_t v = px[4 * y + x];
+          q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16);
+          if (COMPS == 4) q[3] = (uint8_t)(v >> 24);
+        }
+  }
+}
+
+extern "C" {
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_decode_kernel(DecodeParams P) {
+  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+  if (k < P.total_blocks) decode_one<ICAMD_DXT1>(P, k);
+}
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt5_decode_kernel(DecodeParams P) {
+  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+  if (k < P.total_blocks) decode_one<ICAMD_DXT5>(P, k);
+}
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_decode_kernel(DecodeParams P) {
+  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+  if (k < P.total_blocks) decode_one<ICAMD_ETC1>(P, k);
+}
+}  // extern "C"
+
+hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
+  if (P.total_blocks == 0) return hipSuccess;
+  const dim3 grid((P.total_blocks + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
+  if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_dxt1_decode_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_dxt5_decode_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_etc1_decode_kernel, grid, block, 0, stream, P);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 }  // namespace icamd

@@ -319,5 +319,32 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
   return ICAMD_OK;
 }
 
+int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                     const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) {
+  if (!blocks || !out || height == 0 || width == 0) return ICAMD_FALSE;
+  int codec, comps;
+  bool swap;
+  if (!resolve_codec(compressor, format, &codec, &comps, &swap)) return ICAMD_FALSE;
+  if (blocks_size != icamd_encoded_size(codec, height, width)) return ICAMD_FALSE;
+  const size_t need = (size_t)height * ((size_t)width * comps + padding_bytes_per_row);
+  if (out_size != need) return ICAMD_FALSE;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  rc = g_staging.ensure(blocks_size, need);
+  if (rc != ICAMD_OK) return rc;
+  hipStream_t s = g_staging.stream;
+  ICAMD_HIP(hipMemcpyAsync(g_staging.d_in, blocks, blocks_size, hipMemcpyHostToDevice, s), "H2D copy");
+  if (padding_bytes_per_row) ICAMD_HIP(hipMemsetAsync(g_staging.d_out, 0, need, s), "memset");
+  rc = icamd_decode_device(codec, swap, height, width, padding_bytes_per_row, 1, 0, 0, g_staging.d_in,
+                           g_staging.d_out, s);
+  if (rc != ICAMD_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  ICAMD_HIP(hipMemcpyAsync(out, g_staging.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
+  ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
+  return ICAMD_OK;
+}
+
 #pragma GCC visibility pop
 }  // extern "C"

@@ -115,6 +115,13 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
                         size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
                         const void *d_blocks, void *d_pixels, void *hip_stream);
 
+/* Host-buffer drop-in for Compressor::Decompress (compressor.h:85-86) on DXTC / ETC images: `blocks` holds
+ * the block grid of an image whose metadata says (uncompressed_height, uncompressed_width,
+ * padding_bytes_per_row); `out` receives height rows of width*comps + padding bytes (out_size must be
+ * exactly that).  PVRTC returns ICAMD_FALSE (pvrtc_compressor.cc:669-672). */
+int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
+                     const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size);
+
 /* ---- runtime ---- */
 int icamd_device_count(void);             /* HIP devices visible; 0 if none */
 const char *icamd_last_error(void);       /* thread-local message for the last negative status */

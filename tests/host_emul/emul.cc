@@ -12,6 +12,7 @@
 #include "dxt_block.h"
 #include "etc1_block.h"
 #include "pvrtc_block.h"
+#include "decode_block.h"
 
 using namespace icamd;
 
@@ -39,6 +40,24 @@ extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_
         Out8 c = encode_etc1_block(px, (uint32_t)strategy);
         memcpy(o, &c, 8);
       }
+    }
+  return 1;
+}
+
+extern "C" int emul_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const uint8_t *blocks, uint8_t *out) {
+  const int comps = codec == 1 ? 4 : 3;
+  const uint32_t rows = (h + 3) / 4, cols = (w + 3) / 4;
+  const size_t stride = (size_t)w * comps + pad;
+  for (uint32_t br = 0; br < rows; ++br)
+    for (uint32_t bc = 0; bc < cols; ++bc) {
+      const uint32_t *b = reinterpret_cast<const uint32_t *>(blocks + ((size_t)br * cols + bc) * (codec == 1 ? 16 : 8));
+      uint32_t px[16];
+      if (codec == 1) { decode_dxt_colors(b[2], b[3], swap != 0, true, px); decode_dxt5_alpha(b[0], b[1], px); }
+      else if (codec == 0) decode_dxt_colors(b[0], b[1], swap != 0, false, px);
+      else decode_etc1(b[0], b[1], px);
+      for (uint32_t y = 0; y < 4 && br * 4 + y < h; ++y)
+        for (uint32_t x = 0; x < 4 && bc * 4 + x < w; ++x)
+          memcpy(out + (br * 4 + y) * stride + (size_t)(bc * 4 + x) * comps, &px[4 * y + x], comps);
     }
   return 1;
 }

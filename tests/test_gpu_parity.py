@@ -204,3 +204,30 @@ def test_pvrtc_batch_and_full_size_4096(pkg):
         return r
     for (bx, by) in [(0, 0), (5, 7), (31, 63), (16, 16), (17, 3)]:
         assert a[z(bx, by)].tobytes() == b[z((bx + 16) % 32, (by + 16) % 64)].tobytes()
+
+
+# ---- "next" row 8f.1: decoders
+
+def test_decoders_match_oracle_and_golden(pkg):
+    import torch
+    for c in G.load("decode_hashes.json"):
+        img = T.s_mixed(c["h"], c["w"], T.comps_of(c["format"]), index=c["index"])
+        comp = c["compressor"]
+        codec = T.ETC1 if comp == T.ETC else (T.DXT1 if T.comps_of(c["format"]) == 3 else T.DXT5)
+        swap = c["format"] in (T.BGR, T.BGRA)
+        blocks = pkg.compress_device(comp, c["format"], _dev(img), c["h"], c["w"])
+        assert hashlib.sha256(_host(blocks)).hexdigest() == c["blocks_sha256"]
+        px = pkg.decode_device(codec, blocks.contiguous(), c["h"], c["w"], swap_rb=swap)
+        assert hashlib.sha256(_host(px)).hexdigest() == c["pixels_sha256"]
+    g = np.random.Generator(np.random.PCG64(11))
+    for codec, comps in ((T.DXT1, 3), (T.DXT5, 4), (T.ETC1, 3)):
+        for (h, w, pad) in [(64, 64, 0), (13, 7, 0), (9, 9, 5), (1024, 1024, 0)]:
+            n = pkg.encoded_size(codec, h, w)
+            blocks = g.integers(0, 256, size=n, dtype=np.uint8)
+            if codec == T.ETC1:
+                b = blocks.reshape(-1, 8)
+                b[:, 3] &= 0xFD  # individual mode only: random differential blocks can leave the valid range
+            want = T.oracle_decode(codec, blocks.tobytes(), h, w, pad=pad)
+            got = pkg.decode_device(codec, _dev(blocks), h, w, padding_bytes_per_row=pad)
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy().reshape(-1), want), (codec, h, w, pad)

@@ -95,3 +95,28 @@ def test_pvrtc_math_matches_oracle(emul):
     img[8:, :, 1] = 200
     img[:, 16:, 3] = 255
     assert emul_encode(emul, T.PVRTC2, img, 32, 32, 4) == T.oracle_encode(T.PVRTC2, img, 32, 32, 4)
+
+
+def test_decode_math_matches_oracle(emul):
+    emul.emul_decode.restype = ctypes.c_int
+    emul.emul_decode.argtypes = [T.ci, T.ci, T.u32, T.u32, T.u32, T.vp, T.vp]
+    g = np.random.Generator(np.random.PCG64(11))
+    for codec, comps in ((T.DXT1, 3), (T.DXT5, 4), (T.ETC1, 3)):
+        for swap in ((0, 1) if codec != T.ETC1 else (0,)):
+            for (h, w, pad) in [(64, 64, 0), (13, 7, 0), (9, 9, 5)]:
+                n = T.oracle().ico_encoded_size(codec, h, w)
+                for kind in ("encoded", "random"):
+                    if kind == "encoded":
+                        blocks = T.oracle_encode(codec, T.s_mixed(h, w, 4 if codec == T.DXT5 else 3, index=3), h, w,
+                                                 4 if codec == T.DXT5 else 3, swap)
+                    else:
+                        blocks = g.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+                        if codec == T.ETC1:  # keep differential base colours in range (valid streams only)
+                            b = np.frombuffer(blocks, np.uint8).copy().reshape(-1, 8)
+                            b[:, 3] &= 0xFD
+                            blocks = b.tobytes()
+                    want = T.oracle_decode(codec, blocks, h, w, swap=swap, pad=pad)
+                    out = np.zeros(h * (w * comps + pad), np.uint8)
+                    bb = np.frombuffer(blocks, np.uint8)
+                    assert emul.emul_decode(codec, swap, h, w, pad, bb.ctypes.data, out.ctypes.data)
+                    assert np.array_equal(out, want), (codec, swap, h, w, pad, kind)
