@@ -173,12 +173,12 @@ def main():
 
     gather_ms = None
     if args.gather and world > 1:
-        gathered = torch.empty((world,) + tuple(out.shape), dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(gathered, out)  # warm-up (communicator set-up)
+        from image_compression_amd import sharding
+        gathered = sharding.gather_output(out, world)  # warm-up (communicator set-up)
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, out)
+        gathered = sharding.gather_output(out, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert torch.equal(gathered[rank], out)

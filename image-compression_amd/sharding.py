@@ -1,0 +1,66 @@
+"""Multi-GPU sharding of the block-encode path: one process per GPU, `torch.distributed` (backend "nccl" =
+RCCL over xGMI on MI355X; "gloo" in the CPU test tier).
+
+Every 4x4 (DXT/ETC) block and every PVRTC texture is independent, so there is NO collective on the data path:
+  * a batch of textures is split into contiguous per-rank ranges (`texture_range`);
+  * one large DXT/ETC image is split into contiguous slabs of block rows (`block_row_range`); blocks are stored
+    row-major (reference compressor4x4_helper.h:202-214), so each slab's output is one contiguous byte range.
+The only exchange is the optional gather of the compressed output (1/6..1/8 of the input bytes), `gather_output`.
+"""
+import torch
+import torch.distributed as dist
+
+
+def texture_range(n_textures, world_size, rank):
+    """Contiguous, balanced split of [0, n_textures) -> (begin, end) for `rank`."""
+    return n_textures * rank // world_size, n_textures * (rank + 1) // world_size
+
+
+def block_row_range(block_rows, world_size, rank):
+    """Contiguous, balanced split of a single image's block rows -> (begin, end)."""
+    return block_rows * rank // world_size, block_rows * (rank + 1) // world_size
+
+
+def slab_geometry(height, width, components, row_stride_bytes, block_bytes, world_size, rank):
+    """For one DXT/ETC image sharded by block rows: what this rank reads and where its blocks go.
+    Returns dict(pixel_row0, pixel_rows, src_offset_bytes, dst_offset_bytes, dst_bytes).  The last slab keeps the
+    image's ragged bottom edge, so edge replication (pixel4x4.cc:23-59) is unchanged."""
+    rows = (height + 3) // 4
+    cols = (width + 3) // 4
+    b0, b1 = block_row_range(rows, world_size, rank)
+    y0 = b0 * 4
+    y1 = min(height, b1 * 4)
+    return {"block_row0": b0, "block_rows": b1 - b0, "pixel_row0": y0, "pixel_rows": max(0, y1 - y0),
+            "src_offset_bytes": y0 * row_stride_bytes, "dst_offset_bytes": b0 * cols * block_bytes,
+            "dst_bytes": (b1 - b0) * cols * block_bytes}
+
+
+def gather_output(local, world_size, dst=None, group=None):
+    """Gathers equally sized per-rank compressed buffers.  dst=None: all-gather (every rank gets
+    [world, ...]); dst=r: only rank r receives (others get None).  One collective, after the encode."""
+    if world_size == 1:
+        return local.unsqueeze(0)
+    if dst is None:
+        local = local.contiguous()
+        flat = torch.empty((world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device)  # concatenation along dim 0: the layout both RCCL and gloo accept
+        dist.all_gather_into_tensor(flat, local, group=group)
+        return flat.view((world_size,) + tuple(local.shape))
+    rank = dist.get_rank(group)
+    bufs = [torch.empty_like(local) for _ in range(world_size)] if rank == dst else None
+    dist.gather(local.contiguous(), bufs, dst=dst, group=group)
+    return torch.stack(bufs) if rank == dst else None
+
+
+def encode_batch_sharded(encode_fn, textures, world_size, rank, gather_dst=None, gather=True):
+    """textures: [n, h, w, c] uint8 tensor visible to every rank (or just this rank's slice semantics: only
+    textures[begin:end] is touched).  encode_fn(batch[k,h,w,c]) -> [k, bytes] uint8 tensor.
+    Returns (local_output, gathered or None).  n must divide evenly for the gather (equal counts)."""
+    n = textures.shape[0]
+    b, e = texture_range(n, world_size, rank)
+    local = encode_fn(textures[b:e])
+    if not gather or world_size == 1:
+        return local, (local.unsqueeze(0) if gather else None)
+    if n % world_size != 0:
+        raise ValueError("gather needs n_textures divisible by world_size (equal per-rank counts)")
+    return local, gather_output(local, world_size, dst=gather_dst)

@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 `gloo` process group.  The sharding / gather logic of
+image-compression_amd/sharding.py is exercised with the ORACLE standing in for the device encoder (tests only);
+the assembled result must equal the oracle's output for the whole batch / whole image."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ic_testlib as T
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_sharding():
+    import importlib.util
+    path = os.path.join(T.ROOT, "image-compression_amd", "sharding.py")
+    spec = importlib.util.spec_from_file_location("icamd_sharding", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = _load_sharding()
+    ok = True
+    # (1) batch of independent textures, ETC1 (config 4 shape in miniature) + PVRTC
+    for codec, comps, size in ((T.ETC1, 3, 32), (T.PVRTC2, 4, 32), (T.DXT1, 4, 20)):
+        n = 6
+        batch = np.stack([T.s_mixed(size, size, comps, index=i) for i in range(n)])
+
+        def enc(t):
+            arr = t.numpy()
+            outs = [np.frombuffer(T.oracle_encode(codec, arr[i], size, size, comps), np.uint8) for i in range(arr.shape[0])]
+            return torch.from_numpy(np.stack(outs).copy())
+        local, gathered = sh.encode_batch_sharded(enc, torch.from_numpy(batch), world, rank)
+        full = np.stack([np.frombuffer(T.oracle_encode(codec, batch[i], size, size, comps), np.uint8) for i in range(n)])
+        ok &= bool(np.array_equal(gathered.reshape(n, -1).numpy(), full))
+        # gather to rank 0 only
+        _, g0 = sh.encode_batch_sharded(enc, torch.from_numpy(batch), world, rank, gather_dst=0)
+        if rank == 0:
+            ok &= bool(np.array_equal(g0.reshape(n, -1).numpy(), full))
+        else:
+            ok &= g0 is None
+    # (2) one large DXT5 image sharded by block rows, ragged height, row padding
+    h, w, comps, pad = 37, 29, 4, 5
+    img = T.s_mixed(h, w, comps, index=3)
+    src = T.with_row_padding(img, pad)
+    stride = w * comps + pad
+    geo = sh.slab_geometry(h, w, comps, stride, 16, world, rank)
+    slab_src = src[geo["src_offset_bytes"]:]
+    # the slab is encoded as its own image; only the LAST slab may be ragged / replicate the bottom edge
+    slab = T.oracle_encode(T.DXT5, slab_src, geo["pixel_rows"], w, comps, stride=stride,
+                           gh=geo["block_rows"] * 4, gw=w)
+    whole = T.oracle_encode(T.DXT5, src, h, w, comps, stride=stride)
+    ok &= slab == whole[geo["dst_offset_bytes"]: geo["dst_offset_bytes"] + geo["dst_bytes"]]
+    sizes = [sh.slab_geometry(h, w, comps, stride, 16, world, r)["dst_bytes"] for r in range(world)]
+    ok &= sum(sizes) == len(whole)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    results[rank] = int(flag.item())
+    dist.destroy_process_group()
+
+
+def test_sharded_encode_and_gather_world2():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+        assert dict(results) == {0: 1, 1: 1}
+
+
+def test_ranges_partition_exactly():
+    sh = _load_sharding()
+    for n in (1, 7, 8, 128, 1024):
+        for world in (1, 2, 3, 4, 8):
+            spans = [sh.texture_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
