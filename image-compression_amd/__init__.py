@@ -14,7 +14,7 @@ import os
 import torch  # must precede CDLL: libic_amd.so then binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libic_amd.so")
+LIB_PATH = os.environ.get("ICAMD_LIB_PATH", os.path.join(_HERE, "libic_amd.so"))  # override: A/B experiments only
 
 # enums of include/ic_amd.h
 COMPRESSOR_DXTC, COMPRESSOR_ETC, COMPRESSOR_PVRTC = 0, 1, 2

@@ -12,12 +12,19 @@
 #define ICAMD_PVRTC_BLOCK_H_
 
 #include "ic_device.h"
+#if defined(ICAMD_HOST_EMULATION)
+#include <string.h>
+#endif
 
 namespace icamd {
 
 // A block's two colours after ApplyColorChannelReduction, expanded to channel pairs.
 struct PvrtcAB {
   uint32_t a_rb, a_ga, b_rb, b_ga;
+};
+// ... and as the two RGBA dwords the morph kernel stores (8 bytes per block).
+struct PvrtcColors {
+  uint32_t a, b;
 };
 
 ICAMD_DEV uint32_t pair_rb(uint32_t c) { return c & 0x00ff00ffu; }
@@ -70,21 +77,27 @@ struct Stash32 {
 // (an IMAGE index, pvrtc.cc:268-269) and only replaces it when a fitness value > 0 is seen.
 // Returns the two extreme colours, ordered so that colour A is not brighter than colour B.
 ICAMD_DEV void pvrtc_extremes(const uint32_t px[32], uint32_t image0, Stash32 &stash, uint32_t &col_a, uint32_t &col_b) {
+  // keys: value*32 + p (min side) and value*32 + (31-p) (max side).  The max-side key is the min-side key
+  // plus (31 - 2p): one full-rate v_add_u32 instead of a second half-rate v_dot4.  Reductions in groups of
+  // two pixels so they become v_min3_u32 / v_max3_u32.
   uint32_t kmin[5], kmax[5];
   ICAMD_UNROLL
   for (int i = 0; i < 5; ++i) { kmin[i] = 0xffffffffu; kmax[i] = 0u; }
   ICAMD_UNROLL
-  for (int p = 0; p < 32; ++p) {
-    const uint32_t c = px[p];
-    // lightness = (77r + 150g + 28b) / 256, then key = lightness*32 + idx
-    const uint32_t l32 = (udot4(c, 0x001c964du, 0u) >> 3) & ~31u;
-    kmin[0] = umin(kmin[0], l32 | (uint32_t)p);
-    kmax[0] = umax(kmax[0], l32 | (uint32_t)(31 - p));
+  for (int p = 0; p < 32; p += 2) {
+    uint32_t lo[2][5];
     ICAMD_UNROLL
-    for (int ch = 0; ch < 4; ++ch) {
-      const uint32_t w = 32u << (8 * ch);
-      kmin[ch + 1] = umin(kmin[ch + 1], udot4(c, w, (uint32_t)p));
-      kmax[ch + 1] = umax(kmax[ch + 1], udot4(c, w, (uint32_t)(31 - p)));
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t c = px[p + q];
+      // lightness = (77r + 150g + 28b) / 256
+      lo[q][0] = ((udot4(c, 0x001c964du, 0u) >> 3) & ~31u) | (uint32_t)(p + q);
+      ICAMD_UNROLL
+      for (int ch = 0; ch < 4; ++ch) lo[q][ch + 1] = udot4(c, 32u << (8 * ch), (uint32_t)(p + q));
+    }
+    ICAMD_UNROLL
+    for (int i = 0; i < 5; ++i) {
+      kmin[i] = umin3(kmin[i], lo[0][i], lo[1][i]);
+      kmax[i] = umax3(kmax[i], lo[0][i] + (uint32_t)(31 - 2 * p), lo[1][i] + (uint32_t)(31 - 2 * (p + 1)));
     }
   }
   stash.put(px);
@@ -141,6 +154,145 @@ ICAMD_DEV uint32_t pvrtc_pixel_mod(uint32_t pixel, const PvrtcAB nb[3][3]) {
                          bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw));
 }
 
+// v_add_u32 / v_sub_u32 run at twice the rate of shifts-left, multiplies and 3-operand ops on gfx950
+// (measured: scripts/ubench_valu.hip), so doubling is spelled as an add the compiler may not turn into a shift.
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t add_fr(uint32_t a, uint32_t b) { return a + b; }
+#else
+ICAMD_DEV uint32_t add_fr(uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+#endif
+ICAMD_DEV uint32_t times2(uint32_t a) { return add_fr(a, a); }
+// Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
+#else
+ICAMD_DEV uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#endif
+
+// (4-yw)*top + yw*bot on a channel pair (both 16-bit lanes; <= 4*255 per lane).
+ICAMD_DEV uint32_t vblend_pair(uint32_t yw, uint32_t top, uint32_t bot) {
+  if (yw == 0u) return times2(times2(top));
+  if (yw == 2u) return times2(top + bot);
+  return yw == 1u ? 3u * top + bot : top + 3u * bot;
+}
+
+// Modulation value of one pixel from the horizontally accumulated sums P[] = 32 * (up-sampled A_rb, A_ga,
+// B_rb, B_ga); the value (0..3) is ADDED into `acc` at the byte whose unit is `unit` (1, 1<<8, ...).
+// Same decisions as best_modulation(), spelled with full-rate add/sub/and/shift-right wherever possible:
+//   5A+3B = 4(A+B) + (A-B), 3A+5B = 4(A+B) - (A-B)  (plain 32-bit arithmetic on the packed lanes is exact as
+//   long as every lane RESULT is in range, borrows between lanes cancel);
+//   "d1 < d0" is the sign of d1 - d0 smeared by an arithmetic shift.
+ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t unit, uint32_t acc) {
+  const uint32_t kSel = 0x06020400u;  // bytes: lo.b0, hi.b0, lo.b2, hi.b2  = R, G, B, A
+  const uint32_t sa_rb = P[0] >> 5, sa_ga = P[1] >> 5, sb_rb = P[2] >> 5, sb_ga = P[3] >> 5;
+  const uint32_t c0 = perm(sa_ga, sa_rb, kSel), c3 = perm(sb_ga, sb_rb, kSel);
+  const uint32_t a_rb = sa_rb & 0x00ff00ffu, a_ga = sa_ga & 0x00ff00ffu;
+  const uint32_t b_rb = sb_rb & 0x00ff00ffu, b_ga = sb_ga & 0x00ff00ffu;
+  const uint32_t s_rb = times2(times2(a_rb + b_rb)), d_rb = a_rb - b_rb;
+  const uint32_t s_ga = times2(times2(a_ga + b_ga)), d_ga = a_ga - b_ga;
+  const uint32_t c1 = perm((s_ga + d_ga) >> 3, (s_rb + d_rb) >> 3, kSel);
+  const uint32_t c2 = perm((s_ga - d_ga) >> 3, (s_rb - d_rb) >> 3, kSel);
+  const uint32_t d0 = sad_u8(pixel, c0, 0u), d1 = sad_u8(pixel, c1, 0u);
+  const uint32_t d2 = sad_u8(pixel, c2, 0u), d3 = sad_u8(pixel, c3, 0u);
+  const uint32_t t1 = (uint32_t)((int32_t)(d1 - d0) >> 31);
+  const uint32_t t2 = (uint32_t)((int32_t)(d2 - d1) >> 31) & t1;
+  const uint32_t t3 = (uint32_t)((int32_t)(d3 - d2) >> 31) & t2;
+  return acc + (t1 & unit) + (t2 & unit) + (t3 & unit);
+}
+
+// Scheduling fence: keeps hipcc from interleaving independent pixels / rows, which would multiply the live
+// registers (the encode kernel wants <= 64 VGPRs; thread-level parallelism covers the latency instead).
+#if defined(ICAMD_HOST_EMULATION)
+#define ICAMD_SCHED_FENCE() ((void)0)
+ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+#else
+#define ICAMD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__popc(v); }
+#endif
+
+// The 8 modulation values of one pixel row of a block (bytes of row[0..1], x order), and optionally the value of
+// the pixel just right of the row (first pixel of the right-hand block).  top[c] / bot[c], c = 0..2: reduced
+// colours of the block columns (left, centre, right) in the two block rows that bracket this pixel row;
+// yw = vertical weight of `bot` (0..3).  Separable form of pvrtc.cc:173-237: blend the three block columns
+// vertically once ((4-yw)*top + yw*bot), then walk each half row with P(xw+1) = P(xw) + (VR - VL):
+//   x_in 0..3: sources (left, centre), xw = 4..7, P(4) = 4 (VL + VR)
+//   x_in 4..7: sources (centre, right), xw = 0..3, P(0) = 8 VL
+//   pixel right of the row = x_in 0 of the next block: sources (centre, right), xw = 4
+// (a*c00 + b*c01 + c*c10 + d*c11 with a..d = (4-yw)(8-xw), (4-yw)xw, yw(8-xw), yw*xw is exactly
+//  (8-xw)*VL + xw*VR; the division by 32 happens once, in accumulate_mod.)
+template <bool WITH_RIGHT>
+ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const PvrtcColors bot[3], const uint32_t *pixels,
+                              uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
+  uint32_t V[3][4];
+  ICAMD_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    // opaque(): re-expand the colours for every pixel row instead of letting the compiler keep all 36
+    // expanded pairs of the 3x3 neighbourhood alive across the whole block (4 full-rate ops per colour).
+    const uint32_t ta = opaque(top[c].a), tb = opaque(top[c].b), ba = opaque(bot[c].a), bb = opaque(bot[c].b);
+    V[c][0] = vblend_pair(yw, pair_rb(ta), pair_rb(ba));
+    V[c][1] = vblend_pair(yw, pair_ga(ta), pair_ga(ba));
+    V[c][2] = vblend_pair(yw, pair_rb(tb), pair_rb(bb));
+    V[c][3] = vblend_pair(yw, pair_ga(tb), pair_ga(bb));
+  }
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    uint32_t P[4], D[4];
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) {
+      const uint32_t vl = V[h][v], vr = V[h + 1][v];
+      D[v] = vr - vl;
+      P[v] = h == 0 ? times2(times2(vl + vr)) : times2(times2(times2(vl)));
+    }
+    uint32_t acc = 0;
+    ICAMD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      // opaque(): finish this pixel (compares included) before the next one starts, otherwise the optimiser
+      // sinks all eight pixels' decisions to the end of the row and keeps their distances alive until then
+      acc = opaque(accumulate_mod(pixels[4 * h + j], P, 1u << (8 * j), acc));
+      ICAMD_SCHED_FENCE();
+      if (j < 3) {
+        ICAMD_UNROLL
+        for (int v = 0; v < 4; ++v) P[v] = add_fr(P[v], D[v]);
+      }
+    }
+    row[h] = acc;
+  }
+  if (WITH_RIGHT) {
+    uint32_t P[4];
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) P[v] = times2(times2(V[1][v] + V[2][v]));
+    *right_mod = accumulate_mod(right_pixel, P, 1u, 0u);
+  }
+}
+
+// All modulation values a block's encoding depends on, from its 3x3 block neighbourhood nb (toroidal wrap
+// applied by the caller): its own 32 (rows[y][h]: byte x&3 of rows[y][x>>2] = pixel (x, y)), the pixel column
+// right of it (right_col: byte y; right_px[y] = first pixel of row y of the right-hand block) and the pixel row
+// below it (below[0..1]; below_px[0..7] = first pixel row of the block below).  CalculateBlockModulationMode
+// looks one pixel right and one pixel down (pvrtc.cc:416-429), so these 12 extra values make the block
+// self-contained: no exchange with other lanes is needed.
+ICAMD_DEV void pvrtc_block_mods(const uint32_t px[32], const uint32_t right_px[4], const uint32_t below_px[8],
+                                const PvrtcColors nb[3][3], uint32_t rows[4][2], uint32_t *right_col, uint32_t below[2]) {
+  uint32_t rc = 0;
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const int y0 = y < 2 ? 0 : 1;
+    uint32_t m;
+    pvrtc_row_mods<true>((uint32_t)((y + 2) & 3), nb[y0], nb[y0 + 1], &px[8 * y], right_px[y], rows[y], &m);
+    rc |= m << (8 * y);
+  }
+  *right_col = rc;
+  // first pixel row of the block below: y_in = 0 there -> block rows (centre, below), weight 2
+  pvrtc_row_mods<false>(2u, nb[1], nb[2], below_px, 0u, below, nullptr);
+}
+
 // EncodeColors (pvrtc.cc:356-388); colours are the channel-reduced RGBA dwords.
 ICAMD_DEV uint32_t pvrtc_pack_colors(uint32_t ca, uint32_t cb, bool mode_1bpp) {
   const uint32_t ar = bfe(ca, 0, 8), ag = bfe(ca, 8, 8), ab = bfe(ca, 16, 8), aa = ca >> 24;
@@ -158,13 +310,13 @@ ICAMD_DEV uint32_t pvrtc_pack_colors(uint32_t ca, uint32_t cb, bool mode_1bpp) {
 // Returns the 32-bit modulation word; *mode_1bpp tells EncodeColors which flag to store.
 ICAMD_DEV uint32_t pvrtc_block_modulation(const uint32_t rows[4][2], uint32_t right_col, const uint32_t below[2],
                                           bool *mode_1bpp) {
-  // pixels best served by an intermediate value (1 or 2): low bit xor high bit of each byte
-  uint32_t inter = 0, hc = 0, vc = 0;
+  uint32_t inter = 0, hc = 0, vc = 0, d1 = 0, d2 = 0;
   ICAMD_UNROLL
   for (int y = 0; y < 4; ++y) {
     ICAMD_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t r = rows[y][h];
+      // pixels best served by an intermediate value (1 or 2): low bit xor high bit of each byte
 #if defined(ICAMD_HOST_EMULATION)
       inter += (uint32_t)__builtin_popcount((r ^ (r >> 1)) & 0x01010101u);
 #else
@@ -174,11 +326,18 @@ ICAMD_DEV uint32_t pvrtc_block_modulation(const uint32_t rows[4][2], uint32_t ri
       // (the names are swapped there, pvrtc.cc:426-429; kept as the reference computes them).
       const uint32_t down = y < 3 ? rows[y + 1][h] : below[h];
       hc = sad_u8(r, down, hc);
-      // neighbour to the right: bytes shifted by one pixel; the last byte comes from the next
-      // dword of the row or from the right-hand block's first column
+      // neighbour to the right: bytes shifted by one pixel; the last byte comes from the next dword of the
+      // row or from the right-hand block's first column
       const uint32_t next = h == 0 ? rows[y][1] : (bfe(right_col, 8 * y, 8));
-      const uint32_t right = alignbit(next, r, 8);
-      vc = sad_u8(r, right, vc);
+      vc = sad_u8(r, alignbit(next, r, 8), vc);
+      // 1BPP word: bit 8y+x = m >> 1.  The four high bits of a dword's bytes are gathered into a nibble by
+      // one multiply (bit 8j+1 -> bit 24+j; no two partial products collide below bit 28).
+      const int pos = 8 * y + 4 * h;
+      d1 |= ((((r >> 1) & 0x01010101u) * 0x01020408u) >> 24) << pos;
+      // 2BPP word: checkerboard samples ((x^y)&1 == 0), 2 bits each, in raster order: bytes 0,2 of the dword on
+      // even rows, bytes 1,3 on odd rows -> one nibble at the same position as the 1BPP nibble.
+      const uint32_t v = ((y & 1) ? r >> 8 : r) & 0x00030003u;
+      d2 |= ((v | v >> 14) & 0xfu) << pos;
     }
   }
   // modes: 0 = 1BPP, 1 = average-4, 2 = vertical, 3 = horizontal (pvrtc.cc:433-446)
@@ -186,25 +345,71 @@ ICAMD_DEV uint32_t pvrtc_block_modulation(const uint32_t rows[4][2], uint32_t ri
   if (inter <= 4u) mode = 0u;
   else if (vc > 10u && vc > hc * 2u) mode = 2u;
   else if (hc > 10u && hc > vc * 2u) mode = 3u;
-
-  uint32_t d1 = 0, d2 = 0;
-  ICAMD_UNROLL
-  for (int y = 0; y < 4; ++y) {
-    ICAMD_UNROLL
-    for (int x = 0; x < 8; ++x) {
-      const uint32_t m = bfe(rows[y][x >> 2], 8 * (x & 3), 8);
-      d1 |= (m >> 1) << (8 * y + x);  // 1BPP: one bit per pixel, raster order
-      if (((x ^ y) & 1) == 0) {        // 2BPP modes: checkerboard samples, 2 bits each
-        const int bitpos = 2 * (4 * y + (x >> 1));
-        uint32_t bit = m;
-        if (bitpos == 0) bit = mode == 1u ? (m & 2u) : (m | 1u);        // average-4 vs "other"
-        else if (bitpos == 20) bit = mode == 2u ? (m | 1u) : (m & 2u);  // vertical vs horizontal
-        d2 |= bit << bitpos;
-      }
-    }
-  }
+  // The samples at bit 0 (0,0) and bit 20 (4,2) keep only their high bit; the low bit selects the sub-mode
+  // (pvrtc.cc:474-487): bit 0 = "not average-4", bit 20 = "vertical".
+  d2 = mode == 1u ? (d2 & ~1u) : (d2 | 1u);
+  d2 = mode == 2u ? (d2 | 1u << 20) : (d2 & ~(1u << 20));
   *mode_1bpp = mode == 0u;
   return mode == 0u ? d1 : d2;
+}
+
+// Row-streaming form of pvrtc_block_mods + pvrtc_block_modulation: the block is consumed one pixel row at a
+// time (rows 0..3 of the block, then the first row of the block below), so only one row of pixels, its 9
+// modulation values and a handful of counters are live at any moment -- this is what keeps the encode kernel
+// at <= 64 VGPRs (8 waves per SIMD), where the full-rate add/and/shift instructions actually pay off.
+// load(r, pixels[8], &right): r = 0..3 -> pixel row r of the block and the pixel right of it;
+//                             r = 4    -> first pixel row of the block below (right unused).
+
+template <typename RowLoader>
+ICAMD_DEV void pvrtc_encode_block_rows(RowLoader &load, const PvrtcColors nb[3][3], uint32_t *data_out,
+                                       bool *mode_1bpp) {
+  uint32_t inter = 0, hc = 0, vc = 0, d1 = 0, d2 = 0, prev[2] = { 0, 0 };
+  uint32_t cur[8], cur_right = 0, nxt[8], nxt_right = 0;
+  load(0, cur, &cur_right);
+  ICAMD_UNROLL
+  for (int r = 0; r < 5; ++r) {
+    if (r < 4) load(r + 1, nxt, &nxt_right);  // prefetch the next row while this one is processed
+    ICAMD_SCHED_FENCE();
+    uint32_t row[2], right_mod = 0;
+    if (r < 4) {
+      const int y0 = r < 2 ? 0 : 1;
+      pvrtc_row_mods<true>((uint32_t)((r + 2) & 3), nb[y0], nb[y0 + 1], cur, cur_right, row, &right_mod);
+    } else {
+      pvrtc_row_mods<false>(2u, nb[1], nb[2], cur, 0u, row, nullptr);  // y_in = 0 of the block below
+    }
+    if (r > 0) {  // "horizontal_count" = sum |m - m(x, y+1)| (names swapped in the source, pvrtc.cc:426-429)
+      hc = sad_u8(prev[0], row[0], hc);
+      hc = sad_u8(prev[1], row[1], hc);
+    }
+    if (r < 4) {
+      // "vertical_count" = sum |m - m(x+1, y)|: bytes shifted by one pixel, last one from the right-hand block
+      vc = sad_u8(row[0], alignbit(row[1], row[0], 8), vc);
+      vc = sad_u8(row[1], alignbit(right_mod, row[1], 8), vc);
+      ICAMD_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t m = row[h];
+        inter += popcount_u32((m ^ (m >> 1)) & 0x01010101u);  // values 1 or 2: low bit xor high bit
+        const int pos = 8 * r + 4 * h;
+        d1 |= ((((m >> 1) & 0x01010101u) * 0x01020408u) >> 24) << pos;  // 1BPP: bit 8y+x = m >> 1
+        const uint32_t v = ((r & 1) ? m >> 8 : m) & 0x00030003u;         // 2BPP: checkerboard samples
+        d2 |= ((v | v >> 14) & 0xfu) << pos;
+      }
+      prev[0] = row[0];
+      prev[1] = row[1];
+      ICAMD_UNROLL
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+      cur_right = nxt_right;
+    }
+    ICAMD_SCHED_FENCE();
+  }
+  uint32_t mode = 1u;  // 0 = 1BPP, 1 = average-4, 2 = vertical, 3 = horizontal (pvrtc.cc:433-446)
+  if (inter <= 4u) mode = 0u;
+  else if (vc > 10u && vc > hc * 2u) mode = 2u;
+  else if (hc > 10u && hc > vc * 2u) mode = 3u;
+  d2 = mode == 1u ? (d2 & ~1u) : (d2 | 1u);                 // pvrtc.cc:474-487
+  d2 = mode == 2u ? (d2 | 1u << 20) : (d2 & ~(1u << 20));
+  *mode_1bpp = mode == 0u;
+  *data_out = mode == 0u ? d1 : d2;
 }
 
 // FromZOrder inverse (pvrtc.cc:80-86): x occupies the odd bits, y the even bits of the block index.
@@ -232,6 +437,7 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
   PvrtcAB *ab = new PvrtcAB[(size_t)bw * bh];
   uint32_t *ca = new uint32_t[(size_t)bw * bh], *cb = new uint32_t[(size_t)bw * bh];
   uint8_t *mods = new uint8_t[(size_t)n * n];
+  uint32_t *self_right = new uint32_t[(size_t)bw * bh], *self_below = new uint32_t[(size_t)2 * bw * bh];
   for (uint32_t by = 0; by < bh; ++by)
     for (uint32_t bx = 0; bx < bw; ++bx) {
       uint32_t px[32];
@@ -253,9 +459,25 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
       for (int dy = 0; dy < 3; ++dy)
         for (int dx = 0; dx < 3; ++dx)
           nb[dy][dx] = ab[((by + bh + dy - 1) % bh) * bw + (bx + bw + dx - 1) % bw];
-      uint8_t m[32];
-      emul_mods_xy<0, 0>(px, nb, m);
+      uint8_t m[32], m2[32];
+      emul_mods_xy<0, 0>(px, nb, m);  // generic per-pixel path
+      uint32_t rows[4][2], right_px[4], below_px[8], right_col, below[2];
+      for (int y = 0; y < 4; ++y) right_px[y] = img[(size_t)(by * 4 + y) * n + ((bx * 8 + 8) & (n - 1))];
+      for (int x = 0; x < 8; ++x) below_px[x] = img[(size_t)((by * 4 + 4) & (n - 1)) * n + bx * 8 + x];
+      PvrtcColors nbc[3][3];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          const size_t o = ((by + bh + dy - 1) % bh) * bw + (bx + bw + dx - 1) % bw;
+          nbc[dy][dx].a = ca[o];
+          nbc[dy][dx].b = cb[o];
+        }
+      pvrtc_block_mods(px, right_px, below_px, nbc, rows, &right_col, below);  // separable path (what the kernel runs)
+      for (int i = 0; i < 32; ++i) m2[i] = (uint8_t)(rows[i / 8][(i % 8) >> 2] >> (8 * (i & 3)));
+      if (memcmp(m, m2, 32) != 0) return 0;
       for (int i = 0; i < 32; ++i) mods[(size_t)(by * 4 + i / 8) * n + bx * 8 + i % 8] = m[i];
+      self_right[by * bw + bx] = right_col;
+      self_below[2 * (by * bw + bx)] = below[0];
+      self_below[2 * (by * bw + bx) + 1] = below[1];
     }
   for (uint32_t by = 0; by < bh; ++by)
     for (uint32_t bx = 0; bx < bw; ++bx) {
@@ -267,14 +489,35 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
         }
       for (int y = 0; y < 4; ++y) right |= (uint32_t)mods[(size_t)(by * 4 + y) * n + ((bx * 8 + 8) & (n - 1))] << (8 * y);
       for (int x = 0; x < 8; ++x) below[x >> 2] |= (uint32_t)mods[(size_t)((by * 4 + 4) & (n - 1)) * n + bx * 8 + x] << (8 * (x & 3));
+      // the halo values each lane recomputes for itself must equal the neighbours' own values
+      if (right != self_right[by * bw + bx] || below[0] != self_below[2 * (by * bw + bx)] ||
+          below[1] != self_below[2 * (by * bw + bx) + 1]) return 0;
       bool one_bpp;
       const uint32_t data = pvrtc_block_modulation(rows, right, below, &one_bpp);
       const uint32_t colors = pvrtc_pack_colors(ca[by * bw + bx], cb[by * bw + bx], one_bpp);
+      {  // the row-streaming encoder (what the kernel runs) must agree
+        PvrtcColors nbc[3][3];
+        for (int dy = 0; dy < 3; ++dy)
+          for (int dx = 0; dx < 3; ++dx) {
+            const size_t o2 = ((by + bh + dy - 1) % bh) * bw + (bx + bw + dx - 1) % bw;
+            nbc[dy][dx].a = ca[o2];
+            nbc[dy][dx].b = cb[o2];
+          }
+        auto loader = [&](int r, uint32_t *pixels, uint32_t *right_px) {
+          const uint32_t yy = (by * 4 + (uint32_t)r) & (n - 1);
+          for (int x = 0; x < 8; ++x) pixels[x] = img[(size_t)yy * n + bx * 8 + x];
+          *right_px = img[(size_t)yy * n + ((bx * 8 + 8) & (n - 1))];
+        };
+        uint32_t data2;
+        bool one2;
+        pvrtc_encode_block_rows(loader, nbc, &data2, &one2);
+        if (data2 != data || one2 != one_bpp) return 0;
+      }
       uint32_t *o = reinterpret_cast<uint32_t *>(out) + 2 * (size_t)pvrtc_z_index(bx, by);
       o[0] = data;
       o[1] = colors;
     }
-  delete[] ab; delete[] ca; delete[] cb; delete[] mods;
+  delete[] ab; delete[] ca; delete[] cb; delete[] mods; delete[] self_right; delete[] self_below;
   return 1;
 }
 #endif
