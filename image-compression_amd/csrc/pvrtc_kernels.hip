@@ -51,6 +51,49 @@ __device__ __forceinline__ void load_block32(const uint32_t *p, uint32_t n, uint
   }
 }
 
+// Per-thread grow-only device buffer.  Reuse from a different stream waits (on the device) for the previous user.
+struct Workspace {
+  int device = -1;
+  void *ptr = nullptr;
+  size_t capacity = 0;
+  hipEvent_t done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool in_flight = false;
+  ~Workspace() {
+    if (ptr) (void)hipFree(ptr);
+    if (done) (void)hipEventDestroy(done);
+  }
+  hipError_t acquire(size_t bytes, hipStream_t stream, void **out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != device || bytes > capacity) {
+      if (ptr) (void)hipFree(ptr);  // hipFree waits for outstanding work on the buffer
+      ptr = nullptr; capacity = 0; in_flight = false; device = dev;
+      if (done) { (void)hipEventDestroy(done); done = nullptr; }
+      e = hipMalloc(&ptr, bytes);
+      if (e != hipSuccess) return e;
+      capacity = bytes;
+    }
+    if (!done) {
+      e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    if (in_flight && last_stream != stream) {
+      e = hipStreamWaitEvent(stream, done, 0);
+      if (e != hipSuccess) return e;
+    }
+    *out = ptr;
+    return hipSuccess;
+  }
+  hipError_t release(hipStream_t stream) {
+    last_stream = stream;
+    in_flight = true;
+    return hipEventRecord(done, stream);
+  }
+};
+thread_local Workspace g_workspace;
+
 }  // namespace
 
 struct PvrtcLaunch {
@@ -132,8 +175,11 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   if (group > P.n_images) group = P.n_images;
   if (bpi * group >= (1ull << 31)) return hipErrorInvalidValue;
 
+  // Workspace for the reduced colours (8 B per block of one image group).  A grow-only hipMalloc buffer per host
+  // thread: stream-ordered pool memory (hipMallocAsync) proved unusable for producer->consumer kernels on ROCm 7.2
+  // (a reused pool block was observed zero-filled underneath the first kernel; scripts/coh_test.hip).
   uint2 *ab = nullptr;
-  hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ab), (size_t)(bpi * group * sizeof(uint2)), stream);
+  hipError_t e = g_workspace.acquire((size_t)(bpi * group * sizeof(uint2)), stream, reinterpret_cast<void **>(&ab));
   if (e != hipSuccess) return e;
   PvrtcLaunch L;
   L.ab = ab;
@@ -152,7 +198,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
   }
   e = hipGetLastError();
-  const hipError_t e2 = hipFreeAsync(ab, stream);
+  const hipError_t e2 = g_workspace.release(stream);
   return e != hipSuccess ? e : e2;
 }
 

@@ -231,3 +231,13 @@ def test_decoders_match_oracle_and_golden(pkg):
             got = pkg.decode_device(codec, _dev(blocks), h, w, padding_bytes_per_row=pad)
             torch.cuda.synchronize()
             assert np.array_equal(got.cpu().numpy().reshape(-1), want), (codec, h, w, pad)
+
+
+def test_pvrtc_call_sequences_host_api(pkg):
+    # Regression: results must not depend on what ran before in the process (workspace / staging reuse).
+    # A 128^2 image spans two workgroups of each PVRTC kernel, 64^2 and 8^2 only one.
+    big = T.s_mixed(128, 128, 4, index=77)
+    assert pkg.compress_host(T.DXTC, T.BGRA, big.reshape(-1), 128, 128) == T.oracle_compress(T.DXTC, T.BGRA, big, 128, 128)
+    for n in (64, 8, 128, 16, 256, 128, 8, 512, 128):
+        img = T.s_mixed(n, n, 4, index=n + 1)
+        assert pkg.compress_host(T.PVRTC, T.RGBA, img.reshape(-1), n, n) == T.oracle_encode(T.PVRTC2, img, n, n, 4), n
