@@ -130,9 +130,11 @@ def main():
         sys.exit("bench.py needs a GPU: the backend has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     codec, comps, bytes_per_px, label = WORKLOADS[args.workload]
     size, batch = args.size, args.batch
@@ -149,7 +151,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -160,19 +162,19 @@ def main():
         step()
         ends[i].record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     gather_ms = None
-    if args.gather and world > 1:
+    if args.gather and distributed:
         from image_compression_amd import sharding
         gathered = sharding.gather_output(out, world)  # warm-up (communicator set-up)
         torch.cuda.synchronize()
@@ -231,7 +233,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(T, codec, comps, size, args.etc_strategy, host0)
         print(json.dumps(result))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

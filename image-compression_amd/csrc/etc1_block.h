@@ -49,6 +49,13 @@ ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
 ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__popc(v); }
 #endif
 
+// True iff the predicate holds in every active lane of the wave (the emulation has one "lane").
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV bool wave_all(bool p) { return p; }
+#else
+ICAMD_DEV bool wave_all(bool p) { return __all(p ? 1 : 0) != 0; }
+#endif
+
 // ETC1 modifier table (OES_compressed_ETC1_RGB8_texture; etc.cc:101-110): row cw = {a, b, -a, -b}.
 // Packed as bytes so a per-lane codeword can look its row up with two v_bfe.
 constexpr uint32_t kEtcModA_lo = 2u | 5u << 8 | 9u << 16 | 13u << 24;
@@ -120,25 +127,83 @@ struct EtcSubResult {
   uint32_t fields;  // see eval_codeword
 };
 
-// FindBestCodeword (etc.cc:391-409): first codeword with the strictly smallest error.
-template <int FLIP, int S>
-ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const EtcBase &base) {
-  EtcSubResult r;
-  uint32_t v[4];
-  int32_t c[4];
-  build_candidates(base, (uint32_t)kEtcA[0], (uint32_t)kEtcB[0], v, c);
-  r.score = eval_codeword<FLIP, S>(px, v, c, &r.fields);
-  r.cw = 0;
+// Unclamped shortcut.  When base_c +/- b stays inside [0,255] for all three channels, every candidate is
+// v = base + m*(1,1,1) and  E(m) = 2 p.v - |v|^2 = E0 + 2 m s - 3 m^2  with  s = Sum(p) - Sum(base),
+// E0 = 2 p.base - |base|^2.  Then (all comparisons exact integers, same tie rules as etc.cc:366-379):
+//   * the sign of s picks the side: s >= 0 -> {+a, +b} (indices 0,1), s < 0 -> {-a, -b} (indices 2,3);
+//     f(+m) - f(-m) = 4 m s, and s = 0 ties go to the lower index, i.e. the positive side;
+//   * within the side, +/-a wins unless 2b|s| - 3b^2 > 2a|s| - 3a^2 (tie -> a, the lower index).
+// Per pixel and codeword that is 2 v_mad_i32_i24 + v_max_i32 instead of 4 dot4 + 4 shift-adds + 2 max.
+// abs_s[j] = |s| of pixel j of the sub-block.  Returns 4 * Sum_j max_m (2 m s - 3 m^2) (WITHOUT the E0 part);
+// *abits gets, in bits 24..31, bit j = 1 iff pixel j chose modifier magnitude a.
+ICAMD_DEV int32_t eval_codeword_unclamped(const uint32_t abs_s[8], int32_t a, int32_t b, uint32_t *abits) {
+  int32_t sum = 0;
+  uint32_t acc = 0;
   ICAMD_UNROLL
-  for (int cw = 1; cw < 8; ++cw) {
+  for (int j = 0; j < 8; ++j) {
+    const int32_t ka = (int32_t)abs_s[j] * (8 * a) + (1 - 12 * a * a);  // 4 f(a) + 1: a wins ties
+    const int32_t kb = (int32_t)abs_s[j] * (8 * b) + (0 - 12 * b * b);  // 4 f(b)
+    const int32_t m = imax(ka, kb);
+    sum += m;
+    acc = alignbit((uint32_t)m, acc, 1);
+  }
+  *abits = acc;
+  return sum - (int32_t)popcount32(acc);
+}
+
+// 8 bits (bit j = pixel j) -> 16 bits (bit 2j)
+ICAMD_DEV uint32_t spread_bits8(uint32_t v) {
+  v = (v | v << 4) & 0x0f0fu;
+  v = (v | v << 2) & 0x3333u;
+  v = (v | v << 1) & 0x5555u;
+  return v;
+}
+
+// FindBestCodeword (etc.cc:391-409): first codeword with the strictly smallest error.
+// bmin / bmax: smallest / largest channel of the decoded base colour (decides, per codeword and for the whole
+// wave at once, whether the unclamped shortcut applies); sub_sum[]: channel sums of the sub-block's 8 pixels;
+// psum[]: r+g+b of each of the 16 pixels.
+template <int FLIP, int S>
+ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
+                                        const uint32_t bch[3], const uint32_t sub_sum[3]) {
+  const uint32_t bsum = bch[0] + bch[1] + bch[2];
+  const uint32_t bmin = umin3(bch[0], bch[1], bch[2]), bmax = umax3(bch[0], bch[1], bch[2]);
+  // per pixel |s| and the sign bits (bit 24+j = 1 iff s < 0), shared by all unclamped codewords
+  uint32_t abs_s[8], negbits = 0;
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t sp = psum[sub_pixel<FLIP, S>(j)];
+    abs_s[j] = sad_u32(sp, bsum, 0u);
+    negbits = alignbit((sp - bsum) >> 31, negbits, 1);
+  }
+  // 4 * Sum_j E0 = 8 * (base . sub_sum) - 32 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
+  const int32_t e0x4 = 8 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
+                       32 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
+  EtcSubResult r;
+  r.score = 0; r.cw = 0; r.fields = 0;
+  uint32_t fast_mask = 0;  // wave-uniform: bit cw set iff that codeword took the shortcut
+  ICAMD_UNROLL
+  for (int cw = 0; cw < 8; ++cw) {
+    int32_t s;
     uint32_t f;
-    build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
-    const int32_t s = eval_codeword<FLIP, S>(px, v, c, &f);
-    const bool better = s > r.score;
+    if (wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u)) {
+      s = eval_codeword_unclamped(abs_s, kEtcA[cw], kEtcB[cw], &f) + e0x4;
+      fast_mask |= 1u << cw;
+    } else {
+      uint32_t v[4];
+      int32_t c[4];
+      build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
+      s = eval_codeword<FLIP, S>(px, v, c, &f);
+    }
+    const bool better = cw == 0 || s > r.score;
     r.score = better ? s : r.score;
     r.cw = better ? (uint32_t)cw : r.cw;
     r.fields = better ? f : r.fields;
   }
+  // the winner's index fields in the common format (3 - k per pixel, 2 bits, bits 16..31):
+  // shortcut -> high bit = (s >= 0), low bit = (magnitude a chosen)
+  const uint32_t from_fast = (spread_bits8(r.fields >> 24) | spread_bits8((~negbits) >> 24) << 1) << 16;
+  r.fields = ((fast_mask >> r.cw) & 1u) ? from_fast : r.fields;
   return r;
 }
 
@@ -176,7 +241,8 @@ struct EtcFlipResult {
 
 // FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
 template <int FLIP>
-ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t s0[3], const uint32_t s1[3], bool heuristic) {
+ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
+                                    const uint32_t s1[3], bool heuristic) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
   uint32_t q5a[3], q5b[3];
   bool diff_mode = true;
@@ -214,8 +280,8 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t s0[3],
     r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
     r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
   } else {
-    r0 = search_codewords<FLIP, 0>(px, e0);
-    r1 = search_codewords<FLIP, 1>(px, e1);
+    r0 = search_codewords<FLIP, 0>(px, psum, e0, b0, s0);
+    r1 = search_codewords<FLIP, 1>(px, psum, e1, b1, s1);
   }
   EtcFlipResult out;
   out.hi = hi | r0.cw << 5 | r1.cw << 2;
@@ -266,6 +332,9 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
       qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
     }
   }
+  uint32_t psum[16];  // r+g+b per pixel (for the unclamped shortcut)
+  ICAMD_UNROLL
+  for (int p = 0; p < 16; ++p) psum[p] = udot4(px[p], 0x00010101u, 0u);
   uint32_t left[3], right[3], top[3], bottom[3];
   ICAMD_UNROLL
   for (int ch = 0; ch < 3; ++ch) {
@@ -277,10 +346,10 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   EtcFlipResult res;
   bool flip;
   if (strategy == 0u) {  // kSplitHorizontally: top|bottom only
-    res = encode_flip<1>(px, top, bottom, false);
+    res = encode_flip<1>(px, psum, top, bottom, false);
     flip = true;
   } else if (strategy == 1u) {  // kSplitVertically: left|right only
-    res = encode_flip<0>(px, left, right, false);
+    res = encode_flip<0>(px, psum, left, right, false);
     flip = false;
   } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574
     // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
@@ -296,15 +365,15 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
     }
     flip = !(e_lr > e_tb);
     // both partitions are evaluated and the lane's choice selected, which keeps the wave convergent
-    const EtcFlipResult r0 = encode_flip<0>(px, left, right, true);
-    const EtcFlipResult r1 = encode_flip<1>(px, top, bottom, true);
+    const EtcFlipResult r0 = encode_flip<0>(px, psum, left, right, true);
+    const EtcFlipResult r1 = encode_flip<1>(px, psum, top, bottom, true);
     res.hi = flip ? r1.hi : r0.hi;
     res.f0 = flip ? r1.f0 : r0.f0;
     res.f1 = flip ? r1.f1 : r0.f1;
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
-    const EtcFlipResult r0 = encode_flip<0>(px, left, right, false);
-    const EtcFlipResult r1 = encode_flip<1>(px, top, bottom, false);
+    const EtcFlipResult r0 = encode_flip<0>(px, psum, left, right, false);
+    const EtcFlipResult r1 = encode_flip<1>(px, psum, top, bottom, false);
     // error_lr <= error_tb  <=>  score_lr >= score_tb  (same Sum|p|^2 on both sides)
     flip = !(r0.score >= r1.score);
     res.hi = flip ? r1.hi : r0.hi;
