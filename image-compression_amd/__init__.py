@@ -26,7 +26,8 @@ OK, FALSE = 0, 1
 EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
-    "icamd_decode_device", "icamd_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
+    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -64,6 +65,18 @@ def lib():
         L.icamd_decode_device.argtypes = [_ci, _ci, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
         L.icamd_decompress.restype = _ci
         L.icamd_decompress.argtypes = [_ci, _ci, _u32, _u32, _u32, _vp, _sz, _vp, _sz]
+        L.icamd_pad.restype = _ci
+        L.icamd_pad.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _u32, _u32, _vp, _sz]
+        L.icamd_pad_device.restype = _ci
+        L.icamd_pad_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _u32, _u32, _vp, _sz, _vp]
+        L.icamd_downsample.restype = _ci
+        L.icamd_downsample.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _vp, _sz]
+        L.icamd_downsample_device.restype = _ci
+        L.icamd_downsample_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _vp, _sz, _vp]
+        L.icamd_transcode_dxt1_to_etc1.restype = _ci
+        L.icamd_transcode_dxt1_to_etc1.argtypes = [_vp, _sz]
+        L.icamd_transcode_dxt1_to_etc1_device.restype = _ci
+        L.icamd_transcode_dxt1_to_etc1_device.argtypes = [_vp, _sz, _vp]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -176,3 +189,36 @@ def decode_device(codec, blocks, height, width, *, swap_rb=False, padding_bytes_
     if not _check(st, "icamd_decode_device"):
         return None
     return out
+
+
+def _block_bytes(compressor, fmt):
+    return 8 if (compressor == COMPRESSOR_ETC or fmt in (RGB, BGR)) else 16
+
+
+def pad_host(compressor, fmt, blocks, compressed_height, compressed_width, padded_height, padded_width,
+             etc_strategy=ETC_SMALLER_ERROR):
+    """Compressor::Pad for the really-padding case, host buffers.  bytes or None (reference's false)."""
+    import numpy as np
+    b = np.frombuffer(blocks, np.uint8)
+    n = ((padded_height + 3) // 4) * ((padded_width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = np.zeros(max(n, 1), np.uint8)
+    st = lib().icamd_pad(compressor, etc_strategy, fmt, compressed_height, compressed_width, b.ctypes.data,
+                         padded_height, padded_width, out.ctypes.data, n)
+    return out[:n].tobytes() if _check(st, "icamd_pad") else None
+
+
+def downsample_host(compressor, fmt, blocks, height, width, etc_strategy=ETC_SMALLER_ERROR):
+    import numpy as np
+    b = np.frombuffer(blocks, np.uint8)
+    dh, dw = (height + 1) // 2, (width + 1) // 2
+    n = ((dh + 3) // 4) * ((dw + 3) // 4) * _block_bytes(compressor, fmt)
+    out = np.zeros(max(n, 1), np.uint8)
+    st = lib().icamd_downsample(compressor, etc_strategy, fmt, height, width, b.ctypes.data, out.ctypes.data, n)
+    return out[:n].tobytes() if _check(st, "icamd_downsample") else None
+
+
+def transcode_dxt1_to_etc1_host(blocks):
+    import numpy as np
+    b = np.frombuffer(blocks, np.uint8).copy()
+    st = lib().icamd_transcode_dxt1_to_etc1(b.ctypes.data, b.size)
+    return b.tobytes() if _check(st, "icamd_transcode_dxt1_to_etc1") else None

@@ -1,0 +1,158 @@
+// blockops_kernels.hip -- Pad / Downsample / DXT1->ETC1 transcode kernels: one output
+// block per lane, coalesced 8/16-byte block loads and stores.  See blockops_block.h for the per-block math.
+#include "blockops_block.h"
+#include "ic_launch.h"
+#include "ic_amd.h"
+
+namespace icamd {
+
+namespace {
+constexpr int kWords(int codec) { return codec == ICAMD_DXT5 ? 4 : 2; }
+}
+
+template <int CODEC>
+__device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
+  constexpr int W = kWords(CODEC);
+  const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + (size_t)k * W;
+  const bool in_rows = r < P.in_rows, in_cols = c < P.in_cols;
+  const uint32_t sr = in_rows ? r : P.in_rows - 1, sc = in_cols ? c : P.in_cols - 1;
+  const uint32_t *s = src + ((size_t)sr * P.in_cols + sc) * W;
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = s[i];
+  if (in_rows && in_cols) {
+#pragma unroll
+    for (int i = 0; i < W; ++i) dst[i] = w[i];
+    return;
+  }
+  const int kind = in_rows ? kPadColumn : (in_cols ? kPadRow : kPadCorner);  // helper.h:427-470
+  if (CODEC == ICAMD_ETC1) {
+    const Out8 o = etc1_pad_block(w[0], w[1], kind, P.etc_strategy);
+    dst[0] = o.lo; dst[1] = o.hi;
+  } else if (CODEC == ICAMD_DXT1) {
+    dst[0] = w[0];
+    dst[1] = dxt_pad_color_bits(w[1], kind);
+  } else {
+    uint32_t lo24 = w[0] >> 16 | (w[1] & 0xffu) << 16, hi24 = w[1] >> 8;
+    dxt5_pad_alpha_codes(lo24, hi24, kind);
+    dst[0] = (w[0] & 0xffffu) | lo24 << 16;
+    dst[1] = lo24 >> 16 | hi24 << 8;
+    dst[2] = w[2];
+    dst[3] = dxt_pad_color_bits(w[3], kind);
+  }
+}
+
+template <int CODEC>
+__device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t k, BlockStash &stash) {
+  constexpr int W = kWords(CODEC);
+  const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src);
+  uint32_t px[16], tmp[16];
+  if (P.in_rows > 1 && P.in_cols > 1) {  // DownsampleBlocks2x2
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        decode_any<CODEC>(src + ((size_t)(2 * r + i) * P.in_cols + 2 * c + j) * W, tmp);
+        store_downsampled(tmp, 2 * i, 2 * j, px);
+      }
+  } else if (P.in_rows > 1) {  // DownsampleBlocks2x1: one block column
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      decode_any<CODEC>(src + (size_t)(2 * r + i) * W, tmp);
+      store_downsampled(tmp, 2 * i, 0, px);
+      store_downsampled(tmp, 2 * i, 2, px);
+    }
+  } else if (P.in_cols > 1) {  // DownsampleBlocks1x2: one block row
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      decode_any<CODEC>(src + (size_t)(2 * c + j) * W, tmp);
+      store_downsampled(tmp, 0, 2 * j, px);
+      store_downsampled(tmp, 2, 2 * j, px);
+    }
+  } else {  // a single block of 4, 2 or 1 pixels per side: replicate to 4x4 first (helper.h:338-387)
+    decode_any<CODEC>(src, tmp);
+    if (P.src_width == 1) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) tmp[4 * y + 1] = tmp[4 * y + 2] = tmp[4 * y + 3] = tmp[4 * y];
+    } else if (P.src_width == 2) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) { tmp[4 * y + 2] = tmp[4 * y]; tmp[4 * y + 3] = tmp[4 * y + 1]; }
+    }
+    if (P.src_height == 1) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) tmp[4 + x] = tmp[8 + x] = tmp[12 + x] = tmp[x];
+    } else if (P.src_height == 2) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) { tmp[8 + x] = tmp[x]; tmp[12 + x] = tmp[4 + x]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) store_downsampled(tmp, 2 * i, 2 * j, px);
+  }
+  uint32_t out[4];
+  encode_any<CODEC>(px, P.etc_strategy, stash, out);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + (size_t)k * W;
+#pragma unroll
+  for (int i = 0; i < W; ++i) dst[i] = out[i];
+}
+
+#define ICAMD_BLOCKOP_KERNELS(NAME, CODEC)                                                                     \
+  extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pad_##NAME##_kernel(BlockOpParams P) { \
+    const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
+    if (k < P.total_out) pad_one<CODEC>(P, k);                                                                 \
+  }                                                                                                            \
+  extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup)                                           \
+  icamd_downsample_##NAME##_kernel(BlockOpParams P) {                                                          \
+    __shared__ uint32_t lds_px[4][kThreadsPerWorkgroup][4];                                                    \
+    BlockStash stash;                                                                                          \
+    stash.base = &lds_px[0][threadIdx.x][0];                                                                   \
+    const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
+    if (k < P.total_out) downsample_one<CODEC>(P, k, stash);                                                   \
+  }
+
+ICAMD_BLOCKOP_KERNELS(dxt1, ICAMD_DXT1)
+ICAMD_BLOCKOP_KERNELS(dxt5, ICAMD_DXT5)
+ICAMD_BLOCKOP_KERNELS(etc1, ICAMD_ETC1)
+
+extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_to_etc1_kernel(uint2 *blocks, uint32_t n) {
+  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+  if (k >= n) return;
+  const uint2 b = blocks[k];
+  uint32_t px[16];
+  decode_dxt_colors(b.x, b.y, false, false, px);          // DecodeDxt1Block(block, swap = false)
+  const Out8 o = encode_etc1_block(px, 3u);               // EncodeEtc1Block(..., kHeuristic)
+  blocks[k] = make_uint2(o.lo, o.hi);
+}
+
+hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
+  if (P.total_out == 0) return hipSuccess;
+  const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
+  if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_pad_dxt1_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_pad_dxt5_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_pad_etc1_kernel, grid, block, 0, stream, P);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream) {
+  if (P.total_out == 0) return hipSuccess;
+  const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
+  if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_downsample_dxt1_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_downsample_dxt5_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_downsample_etc1_kernel, grid, block, 0, stream, P);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_transcode_dxt1_to_etc1(void *blocks, uint32_t n_blocks, hipStream_t stream) {
+  if (n_blocks == 0) return hipSuccess;
+  const dim3 grid((n_blocks + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
+  hipLaunchKernelGGL(icamd_dxt1_to_etc1_kernel, grid, block, 0, stream, static_cast<uint2 *>(blocks), n_blocks);
+  return hipGetLastError();
+}
+
+}  // namespace icamd

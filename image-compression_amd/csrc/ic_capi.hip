@@ -111,6 +111,31 @@ bool resolve_codec(int compressor, int format, int *codec, int *comps, bool *swa
   return false;
 }
 
+bool blockop_codec(int compressor, int format, int *codec) {
+  int comps;
+  bool swap;
+  return resolve_codec(compressor, format, codec, &comps, &swap);
+}
+
+// host-buffer wrappers: stage in, run, stage out
+template <typename F>
+int staged_blockop(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_size, bool in_place, F &&run) {
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  rc = g_staging.ensure(std::max<size_t>(in_size, 1), std::max<size_t>(out_size, 1));
+  if (rc != ICAMD_OK) return rc;
+  hipStream_t s = g_staging.stream;
+  ICAMD_HIP(hipMemcpyAsync(g_staging.d_in, in, in_size, hipMemcpyHostToDevice, s), "H2D copy");
+  rc = run(g_staging.d_in, g_staging.d_out, s);
+  if (rc != ICAMD_OK) {
+    (void)hipStreamSynchronize(s);
+    return rc;
+  }
+  ICAMD_HIP(hipMemcpyAsync(out, in_place ? g_staging.d_in : g_staging.d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
+  ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
+  return ICAMD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -344,6 +369,101 @@ int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width
   ICAMD_HIP(hipMemcpyAsync(out, g_staging.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
   ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
   return ICAMD_OK;
+}
+
+// ---- compressed-domain operations
+
+int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const void *d_blocks,
+                     uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) {
+  int codec;
+  if (!d_blocks || !d_out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  icamd::BlockOpParams P;
+  P.in_rows = num_blocks4(ch); P.in_cols = num_blocks4(cw);
+  P.out_rows = num_blocks4(ph); P.out_cols = num_blocks4(pw);
+  if (P.in_rows == 0 || P.in_cols == 0 || P.out_rows < P.in_rows || P.out_cols < P.in_cols) return ICAMD_FALSE;
+  if (out_size != icamd_encoded_size(codec, ph, pw)) return ICAMD_FALSE;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  P.src = static_cast<const uint8_t *>(d_blocks);
+  P.dst = static_cast<uint8_t *>(d_out);
+  const uint64_t total = (uint64_t)P.out_rows * P.out_cols;
+  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  P.total_out = (uint32_t)total;
+  P.etc_strategy = (uint32_t)etc_strategy;
+  P.src_height = ch; P.src_width = cw;
+  P.div_out_cols = icamd::make_fastdiv(P.out_cols);
+  ICAMD_HIP(icamd::launch_pad(codec, P, static_cast<hipStream_t>(hip_stream)), "launch pad");
+  return ICAMD_OK;
+}
+
+int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw,
+                            const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) {
+  int codec;
+  if (!d_blocks || !d_out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  icamd::BlockOpParams P;
+  P.in_rows = num_blocks4(uh); P.in_cols = num_blocks4(uw);
+  // helper.h:281-284, :340-341
+  if ((P.in_rows > 1 && P.in_rows % 2) || (P.in_cols > 1 && P.in_cols % 2)) return ICAMD_FALSE;
+  if (P.in_rows == 1 && P.in_cols == 1 && (uh == 3 || uw == 3)) return ICAMD_FALSE;
+  const uint32_t dh = (uh + 1) / 2, dw = (uw + 1) / 2;
+  P.out_rows = num_blocks4(dh); P.out_cols = num_blocks4(dw);
+  if (out_size != icamd_encoded_size(codec, dh, dw)) return ICAMD_FALSE;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  P.src = static_cast<const uint8_t *>(d_blocks);
+  P.dst = static_cast<uint8_t *>(d_out);
+  const uint64_t total = (uint64_t)P.out_rows * P.out_cols;
+  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  P.total_out = (uint32_t)total;
+  P.etc_strategy = (uint32_t)etc_strategy;
+  P.src_height = uh; P.src_width = uw;
+  P.div_out_cols = icamd::make_fastdiv(P.out_cols);
+  ICAMD_HIP(icamd::launch_downsample(codec, P, static_cast<hipStream_t>(hip_stream)), "launch downsample");
+  return ICAMD_OK;
+}
+
+int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream) {
+  if (!d_blocks) return ICAMD_FALSE;
+  if (n_bytes / 8 >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  if (n_bytes < 8) return ICAMD_OK;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  ICAMD_HIP(icamd::launch_transcode_dxt1_to_etc1(d_blocks, (uint32_t)(n_bytes / 8), static_cast<hipStream_t>(hip_stream)),
+            "launch transcode");
+  return ICAMD_OK;
+}
+
+int icamd_pad(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks,
+              uint32_t ph, uint32_t pw, uint8_t *out, size_t out_size) {
+  int codec;
+  if (!blocks || !out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  if (num_blocks4(ph) < num_blocks4(ch) || num_blocks4(pw) < num_blocks4(cw)) return ICAMD_FALSE;
+  if (out_size != icamd_encoded_size(codec, ph, pw)) return ICAMD_FALSE;
+  return staged_blockop(blocks, icamd_encoded_size(codec, ch, cw), out, out_size, false,
+                        [&](void *din, void *dout, hipStream_t s) {
+                          return icamd_pad_device(compressor, etc_strategy, format, ch, cw, din, ph, pw, dout, out_size, s);
+                        });
+}
+
+int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, const uint8_t *blocks,
+                     uint8_t *out, size_t out_size) {
+  int codec;
+  if (!blocks || !out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  const uint32_t r = num_blocks4(uh), c = num_blocks4(uw);
+  if ((r > 1 && r % 2) || (c > 1 && c % 2) || (r == 1 && c == 1 && (uh == 3 || uw == 3))) return ICAMD_FALSE;
+  if (out_size != icamd_encoded_size(codec, (uh + 1) / 2, (uw + 1) / 2)) return ICAMD_FALSE;
+  return staged_blockop(blocks, icamd_encoded_size(codec, uh, uw), out, out_size, false,
+                        [&](void *din, void *dout, hipStream_t s) {
+                          return icamd_downsample_device(compressor, etc_strategy, format, uh, uw, din, dout, out_size, s);
+                        });
+}
+
+int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes) {
+  if (!blocks) return ICAMD_FALSE;
+  if (n_bytes < 8) return ICAMD_OK;
+  return staged_blockop(blocks, n_bytes, blocks, n_bytes - n_bytes % 8, true, [&](void *din, void *, hipStream_t s) {
+    return icamd_transcode_dxt1_to_etc1_device(din, n_bytes, s);
+  });
 }
 
 #pragma GCC visibility pop

@@ -36,6 +36,21 @@ struct DecodeParams {
 };
 hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream);
 
+// Compressed-domain operations on one image's block grid.
+struct BlockOpParams {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint32_t in_rows, in_cols;    // source block grid
+  uint32_t out_rows, out_cols;  // result block grid
+  uint32_t total_out;
+  uint32_t etc_strategy;
+  uint32_t src_height, src_width;  // uncompressed pixels of the source (Downsample's single-block case)
+  FastDiv div_out_cols;
+};
+hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream);
+hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream);
+hipError_t launch_transcode_dxt1_to_etc1(void *blocks, uint32_t n_blocks, hipStream_t stream);
+
 const char *dxt_kernel_name(int codec, int comps);
 const char *etc1_kernel_name(int comps);
 const char *pvrtc2_kernel_name();

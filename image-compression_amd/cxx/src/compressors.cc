@@ -6,6 +6,7 @@
 // other error channel, and there is deliberately no CPU fallback.
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,7 @@
 #include "image_compression/public/compressed_image.h"
 #include "image_compression/public/compressor.h"
 #include "image_compression/public/dxtc_compressor.h"
+#include "image_compression/public/dxtc_to_etc_transcoder.h"
 #include "image_compression/public/etc_compressor.h"
 #include "image_compression/public/pvrtc_compressor.h"
 
@@ -78,6 +80,76 @@ bool Decompress4x4(const CompressedImage &image, int compressor, std::vector<uin
   return ok;
 }
 
+// Compressor4x4Helper::Pad (compressor4x4_helper.h:393-477).
+bool Pad4x4(const CompressedImage &image, int compressor, int etc_strategy, uint32 padded_height, uint32 padded_width,
+            CompressedImage *padded_image) {
+  const CompressedImage::Metadata &m = image.GetMetadata();
+  if (m.compressed_height >= padded_height && m.compressed_width >= padded_width) {
+    padded_image->Duplicate(image);  // nothing to pad: plain copy (helper.h:404-408)
+    return true;
+  }
+  // The reference overruns its buffers when exactly one padded dimension has fewer blocks than the image; refuse.
+  if (BlocksFor(padded_height) < BlocksFor(m.compressed_height) || BlocksFor(padded_width) < BlocksFor(m.compressed_width))
+    return false;
+  const size_t data_size = icamd_compute_compressed_data_size(compressor, m.format, padded_height, padded_width);
+  const CompressedImage::Metadata metadata(m.format, m.compressor_name, padded_height, padded_width,
+                                           4 * BlocksFor(padded_height), 4 * BlocksFor(padded_width), 0);
+  if (!PrepareImage(metadata, data_size, padded_image)) return false;
+  return ReportStatus(icamd_pad(compressor, etc_strategy, m.format, m.compressed_height, m.compressed_width,
+                                image.GetData(), padded_height, padded_width, padded_image->GetMutableData(), data_size),
+                      "icamd_pad");
+}
+
+// Compressor4x4Helper::Downsample (compressor4x4_helper.h:264-391).
+bool Downsample4x4(const CompressedImage &image, int compressor, int etc_strategy, CompressedImage *downsampled) {
+  const CompressedImage::Metadata &m = image.GetMetadata();
+  const uint32 rows = BlocksFor(m.uncompressed_height), cols = BlocksFor(m.uncompressed_width);
+  if ((rows > 1 && rows % 2 != 0) || (cols > 1 && cols % 2 != 0)) return false;
+  const uint32 dh = (m.uncompressed_height + 1) / 2, dw = (m.uncompressed_width + 1) / 2;
+  const size_t data_size = icamd_compute_compressed_data_size(compressor, m.format, dh, dw);
+  const CompressedImage::Metadata metadata(m.format, m.compressor_name, dh, dw, 4 * BlocksFor(dh), 4 * BlocksFor(dw), 0);
+  if (!PrepareImage(metadata, data_size, downsampled)) return false;
+  // (like the reference, the single-block case can still fail after the image was set up: 3-pixel sides)
+  return ReportStatus(icamd_downsample(compressor, etc_strategy, m.format, m.uncompressed_height, m.uncompressed_width,
+                                       image.GetData(), downsampled->GetMutableData(), data_size),
+                      "icamd_downsample");
+}
+
+// Compressor4x4Helper::CreateSolidImage (compressor4x4_helper.h:522-543): one block, replicated.  Pure byte
+// shuffling on the host -- there is no per-pixel work to offload.
+bool Solid4x4(const char *name, CompressedImage::Format format, uint32 height, uint32 width, const uint8 *block,
+              size_t block_size, CompressedImage *image) {
+  const size_t count = (size_t)BlocksFor(height) * BlocksFor(width);
+  const CompressedImage::Metadata metadata(format, name, height, width, 4 * BlocksFor(height), 4 * BlocksFor(width), 0);
+  if (!PrepareImage(metadata, count * block_size, image)) return false;
+  for (size_t i = 0; i < count; ++i) std::memcpy(image->GetMutableData() + i * block_size, block, block_size);
+  return true;
+}
+
+// Compressor4x4Helper::CopySubimage (compressor4x4_helper.h:545-592): block-row memcpys.
+bool Subimage4x4(const CompressedImage &image, size_t block_size, uint32 start_row, uint32 start_column, uint32 height,
+                 uint32 width, CompressedImage *subimage) {
+  const CompressedImage::Metadata &m = image.GetMetadata();
+  if (start_row % 4 != 0 || start_column % 4 != 0 || height % 4 != 0 || width % 4 != 0 ||
+      start_row > m.compressed_height || start_column > m.compressed_width ||
+      start_row + height > m.compressed_height || start_column + width > m.compressed_width)
+    return false;
+  const uint32 sub_rows = BlocksFor(height), sub_cols = BlocksFor(width), src_cols = BlocksFor(m.compressed_width);
+  const CompressedImage::Metadata metadata(m.format, m.compressor_name, height, width, 4 * sub_rows, 4 * sub_cols, 0);
+  if (!PrepareImage(metadata, (size_t)sub_rows * sub_cols * block_size, subimage)) return false;
+  const uint8 *src = image.GetData() + ((size_t)(start_row / 4) * src_cols + start_column / 4) * block_size;
+  uint8 *dst = subimage->GetMutableData();
+  for (uint32 r = 0; r < sub_rows; ++r)
+    std::memcpy(dst + (size_t)r * sub_cols * block_size, src + (size_t)r * src_cols * block_size, sub_cols * block_size);
+  return true;
+}
+
+// Quantize8<n> (color_util.h:156-164)
+uint32 Quantize(uint32 v, uint32 bits) {
+  const uint32 i = v * ((1u << bits) - 1u) + 128u;
+  return (i + (i >> 8)) >> 8;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ DXTC
@@ -117,14 +189,41 @@ bool DxtcCompressor::Decompress(const CompressedImage &image, std::vector<uint8>
   return Decompress4x4(image, ICAMD_COMPRESSOR_DXTC, decompressed_buffer);
 }
 
-// Compressed-domain editing is not part of this round's hot path.
-bool DxtcCompressor::Downsample(const CompressedImage &, CompressedImage *) { return false; }
-bool DxtcCompressor::Pad(const CompressedImage &, uint32, uint32, CompressedImage *) { return false; }
-bool DxtcCompressor::CreateSolidImage(CompressedImage::Format, uint32, uint32, const uint8 *, CompressedImage *) {
-  return false;
+bool DxtcCompressor::Downsample(const CompressedImage &image, CompressedImage *downsampled_image) {
+  if (!IsValidCompressedImage(image) || !downsampled_image) return false;
+  return Downsample4x4(image, ICAMD_COMPRESSOR_DXTC, 0, downsampled_image);
 }
-bool DxtcCompressor::CopySubimage(const CompressedImage &, uint32, uint32, uint32, uint32, CompressedImage *) {
-  return false;
+
+bool DxtcCompressor::Pad(const CompressedImage &image, uint32 padded_height, uint32 padded_width,
+                         CompressedImage *padded_image) {
+  if (!IsValidCompressedImage(image) || !padded_image) return false;
+  return Pad4x4(image, ICAMD_COMPRESSOR_DXTC, 0, padded_height, padded_width, padded_image);
+}
+
+bool DxtcCompressor::CreateSolidImage(CompressedImage::Format format, uint32 height, uint32 width, const uint8 *color,
+                                      CompressedImage *image) {
+  if (!image) return false;
+  // dxtc_compressor.cc:42-49,77-82,820-839: c0 = c1 = RGB565(color) (no red/blue swap), index bits zero;
+  // DXT5 adds alpha0 = alpha1 = color[3] with zero codes in front.
+  const uint32 c565 = Quantize(color[0], 5) << 11 | Quantize(color[1], 6) << 5 | Quantize(color[2], 5);
+  uint8 block[16] = { 0 };
+  uint8 *c = block;
+  size_t size = 8;
+  if (GetNumFormatComponents(format) != 3) {
+    block[0] = block[1] = color[3];
+    c = block + 8;
+    size = 16;
+  }
+  c[0] = c[2] = (uint8)(c565 & 0xff);
+  c[1] = c[3] = (uint8)(c565 >> 8);
+  return Solid4x4("dxtc", format, height, width, block, size, image);
+}
+
+bool DxtcCompressor::CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,
+                                  uint32 width, CompressedImage *subimage) {
+  if (!IsValidCompressedImage(image) || !subimage) return false;
+  return Subimage4x4(image, GetNumFormatComponents(image.GetMetadata().format) == 3 ? 8 : 16, start_row, start_column,
+                     height, width, subimage);
 }
 
 // ------------------------------------------------------------------- ETC
@@ -164,13 +263,31 @@ bool EtcCompressor::Decompress(const CompressedImage &image, std::vector<uint8> 
   return Decompress4x4(image, ICAMD_COMPRESSOR_ETC, decompressed_buffer);
 }
 
-bool EtcCompressor::Downsample(const CompressedImage &, CompressedImage *) { return false; }
-bool EtcCompressor::Pad(const CompressedImage &, uint32, uint32, CompressedImage *) { return false; }
-bool EtcCompressor::CreateSolidImage(CompressedImage::Format, uint32, uint32, const uint8 *, CompressedImage *) {
-  return false;
+bool EtcCompressor::Downsample(const CompressedImage &image, CompressedImage *downsampled_image) {
+  if (!IsValidCompressedImage(image) || !downsampled_image) return false;
+  return Downsample4x4(image, ICAMD_COMPRESSOR_ETC, compression_strategy_, downsampled_image);
 }
-bool EtcCompressor::CopySubimage(const CompressedImage &, uint32, uint32, uint32, uint32, CompressedImage *) {
-  return false;
+
+bool EtcCompressor::Pad(const CompressedImage &image, uint32 padded_height, uint32 padded_width,
+                        CompressedImage *padded_image) {
+  if (!IsValidCompressedImage(image) || !padded_image) return false;
+  return Pad4x4(image, ICAMD_COMPRESSOR_ETC, compression_strategy_, padded_height, padded_width, padded_image);
+}
+
+bool EtcCompressor::CreateSolidImage(CompressedImage::Format format, uint32 height, uint32 width, const uint8 *color,
+                                     CompressedImage *image) {
+  if (!image || format != CompressedImage::kRGB) return false;
+  // CreateSolidBlock (etc_compressor.cc:595-617): differential mode, 5-bit base = color >> 3, zero difference,
+  // codeword 0 twice, all indices 0; stored as big-endian high word, then the (zero) low word.
+  const uint32 hi = 2u | (uint32)(color[0] >> 3) << 27 | (uint32)(color[1] >> 3) << 19 | (uint32)(color[2] >> 3) << 11;
+  const uint8 block[8] = { (uint8)(hi >> 24), (uint8)(hi >> 16), (uint8)(hi >> 8), (uint8)hi, 0, 0, 0, 0 };
+  return Solid4x4("etc", format, height, width, block, 8, image);
+}
+
+bool EtcCompressor::CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,
+                                 uint32 width, CompressedImage *subimage) {
+  if (!IsValidCompressedImage(image) || !subimage) return false;
+  return Subimage4x4(image, 8, start_row, start_column, height, width, subimage);
 }
 
 // ----------------------------------------------------------------- PVRTC
@@ -222,6 +339,13 @@ bool PvrtcCompressor::CreateSolidImage(CompressedImage::Format, uint32, uint32, 
 }
 bool PvrtcCompressor::CopySubimage(const CompressedImage &, uint32, uint32, uint32, uint32, CompressedImage *) {
   return false;
+}
+
+// ------------------------------------------------------------ transcoder
+
+void TranscodeDxt1ToEtc1(CompressedImage *image) {  // dxtc_to_etc_transcoder.cc:29-40: in place, data only
+  ReportStatus(icamd_transcode_dxt1_to_etc1(image->GetMutableData(), image->GetDataSize()),
+               "icamd_transcode_dxt1_to_etc1");
 }
 
 }  // namespace image_codec_compression

@@ -122,6 +122,31 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
 int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                      const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size);
 
+/* ---- "next" rows 8f.2-4: compressed-domain operations on one image's block grid ----
+ * Compressor::Pad (compressor.h:104-106; helper.h:393-477; pad functors dxtc.cc:594-696, etc.cc:645-698) for the
+ * case that really pads: the source grid covers (compressed_height, compressed_width) pixels, the result
+ * (padded_height, padded_width); out_size must be the result's data size.  Returns ICAMD_FALSE for PVRTC and when a
+ * padded dimension has fewer blocks than the source (the reference either just duplicates the image, which the caller
+ * does itself, or overruns its buffer). */
+int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
+                     const void *d_blocks, uint32_t padded_height, uint32_t padded_width, void *d_out, size_t out_size,
+                     void *hip_stream);
+int icamd_pad(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
+              const uint8_t *blocks, uint32_t padded_height, uint32_t padded_width, uint8_t *out, size_t out_size);
+
+/* Compressor::Downsample (compressor.h:95-96; helper.h:264-391,594-636): (uncompressed_height, uncompressed_width)
+ * -> ((h+1)/2, (w+1)/2); decode, 2x2 average, re-encode per output block.  ICAMD_FALSE where the reference refuses
+ * (odd block counts > 1, single block with a 3-pixel side, PVRTC). */
+int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
+                            uint32_t uncompressed_width, const void *d_blocks, void *d_out, size_t out_size,
+                            void *hip_stream);
+int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
+                     uint32_t uncompressed_width, const uint8_t *blocks, uint8_t *out, size_t out_size);
+
+/* TranscodeDxt1ToEtc1 (public/dxtc_to_etc_transcoder.h:24; dxtc_to_etc_transcoder.cc:29-40): in place. */
+int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream);
+int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes);
+
 /* ---- runtime ---- */
 int icamd_device_count(void);             /* HIP devices visible; 0 if none */
 const char *icamd_last_error(void);       /* thread-local message for the last negative status */

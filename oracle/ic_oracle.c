@@ -727,3 +727,193 @@ int ico_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const 
     }
   return 1;
 }
+
+/* --------------------------------------- compressed-domain operations (8f rows 2-4) -- */
+
+static int fmt_comps(int format) { return (format == ICO_RGB || format == ICO_BGR) ? 3 : 4; }
+static int block_codec(int compressor, int format) {
+  if (compressor == ICO_COMPRESSOR_ETC) return ICO_ETC1;
+  return fmt_comps(format) == 3 ? ICO_DXT1 : ICO_DXT5;
+}
+
+/* etc.cc:595-617 (CreateSolidBlock): differential mode, 5-bit base = color >> 3, zero difference, codewords 0,
+ * indices 0 (the "adjusted_color" computed there is unused). */
+static void etc_solid_block(const uint8_t color[3], uint8_t out[8]) {
+  uint32_t hi = 2u | (uint32_t)(color[0] >> 3) << 27 | (uint32_t)(color[1] >> 3) << 19 | (uint32_t)(color[2] >> 3) << 11;
+  out[0] = (uint8_t)(hi >> 24); out[1] = (uint8_t)(hi >> 16); out[2] = (uint8_t)(hi >> 8); out[3] = (uint8_t)hi;
+  out[4] = out[5] = out[6] = out[7] = 0;
+}
+
+int ico_create_solid(int compressor, int format, uint32_t h, uint32_t w, const uint8_t *color, uint8_t *out) {
+  if (compressor == ICO_COMPRESSOR_PVRTC) return 0;                        /* pvrtc.cc:693-698 */
+  if (compressor == ICO_COMPRESSOR_ETC && format != ICO_RGB) return 0;     /* etc.cc:805-806 */
+  uint8_t blk[16];
+  size_t bb;
+  if (compressor == ICO_COMPRESSOR_ETC) { etc_solid_block(color, blk); bb = 8; }
+  else {
+    /* dxtc.cc:42-49,77-82: c0 = c1 = Quantize565(color) with NO red/blue swap, all index bits 0 */
+    rgb_t c = { color[0], color[1], color[2] };
+    int p = pack565(quant565(c));
+    uint8_t d1[8] = { (uint8_t)(p & 0xff), (uint8_t)(p >> 8), (uint8_t)(p & 0xff), (uint8_t)(p >> 8), 0, 0, 0, 0 };
+    if (fmt_comps(format) == 3) { memcpy(blk, d1, 8); bb = 8; }
+    else { memset(blk, 0, 8); blk[0] = blk[1] = color[3]; memcpy(blk + 8, d1, 8); bb = 16; }
+  }
+  size_t n = (size_t)nblk(h) * nblk(w);
+  for (size_t i = 0; i < n; ++i) memcpy(out + i * bb, blk, bb);
+  return 1;
+}
+
+int ico_copy_subimage(int compressor, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks, uint32_t row,
+                      uint32_t col, uint32_t h, uint32_t w, uint8_t *out) {
+  if (compressor == ICO_COMPRESSOR_PVRTC) return 0;
+  if (row % 4 || col % 4 || h % 4 || w % 4 || row > ch || col > cw || row + h > ch || col + w > cw) return 0;
+  size_t bb = block_bytes(block_codec(compressor, format));
+  uint32_t ocols = nblk(cw), scols = nblk(w), srows = nblk(h);
+  for (uint32_t r = 0; r < srows; ++r)
+    memcpy(out + (size_t)r * scols * bb, blocks + ((size_t)(row / 4 + r) * ocols + col / 4) * bb, (size_t)scols * bb);
+  return 1;
+}
+
+/* DXT5 alpha codes as a 48-bit integer */
+static uint64_t get_codes48(const uint8_t *b) { uint64_t v = 0; for (int i = 0; i < 6; ++i) v |= (uint64_t)b[2 + i] << (8 * i); return v; }
+static void put_codes48(uint8_t *b, uint64_t v) { for (int i = 0; i < 6; ++i) b[2 + i] = (uint8_t)(v >> (8 * i)); }
+
+/* kind: 0 = column pad (replicate pixel column 3), 1 = row pad (replicate pixel row 3), 2 = corner (pixel (3,3)) */
+static void pad_block(int codec, int etc_strategy, int kind, const uint8_t *src, uint8_t *dst) {
+  if (codec == ICO_ETC1) { /* etc.cc:645-698: decode, replicate, re-encode (corner: solid block) */
+    uint8_t px[16][4];
+    decode_block(ICO_ETC1, 0, src, px);
+    if (kind == 2) { etc_solid_block(px[15], dst); return; }
+    block4x4_t b;
+    b.one_pixel = 0;
+    for (int y = 0; y < 4; ++y)
+      for (int x = 0; x < 4; ++x) {
+        const uint8_t *s = kind == 0 ? px[4 * y + 3] : px[12 + x];
+        b.px[4 * y + x].r = s[0]; b.px[4 * y + x].g = s[1]; b.px[4 * y + x].b = s[2];
+        b.alpha[4 * y + x] = 255;
+      }
+    encode_etc1_block(&b, etc_strategy, dst);
+    return;
+  }
+  /* dxtc.cc:594-696: same endpoints, index bits edited */
+  size_t bb = block_bytes(codec);
+  memcpy(dst, src, bb);
+  uint8_t *cb = dst + (codec == ICO_DXT5 ? 8 : 0);
+  const uint8_t *sb = src + (codec == ICO_DXT5 ? 8 : 0);
+  for (int r = 0; r < 4; ++r) {
+    if (kind == 0) cb[4 + r] = (uint8_t)(((sb[4 + r] >> 6) & 3) * 0x55);
+    else if (kind == 1) cb[4 + r] = sb[7];
+    else cb[4 + r] = (uint8_t)(((sb[7] >> 6) & 3) * 0x55);
+  }
+  if (codec == ICO_DXT5) {
+    uint64_t c = get_codes48(src), o = 0;
+    for (int p = 0; p < 16; ++p) {
+      int sp = kind == 0 ? 4 * (p / 4) + 3 : kind == 1 ? 12 + (p % 4) : 15;
+      o |= ((c >> (3 * sp)) & 7u) << (3 * p);
+    }
+    put_codes48(dst, o);
+  }
+}
+
+int ico_pad(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks,
+            uint32_t ph, uint32_t pw, uint8_t *out) {
+  if (compressor == ICO_COMPRESSOR_PVRTC) return 0;
+  int codec = block_codec(compressor, format);
+  size_t bb = block_bytes(codec);
+  uint32_t orows = nblk(ch), ocols = nblk(cw);
+  if (ch >= ph && cw >= pw) { memcpy(out, blocks, (size_t)orows * ocols * bb); return 2; } /* helper.h:404-408 */
+  uint32_t prows = nblk(ph), pcols = nblk(pw);
+  if (prows < orows || pcols < ocols) return 0; /* the reference overruns its buffer here */
+  for (uint32_t r = 0; r < prows; ++r)
+    for (uint32_t c = 0; c < pcols; ++c) {
+      uint8_t *o = out + ((size_t)r * pcols + c) * bb;
+      if (r < orows && c < ocols) memcpy(o, blocks + ((size_t)r * ocols + c) * bb, bb);
+      else if (r < orows) pad_block(codec, etc_strategy, 0, blocks + ((size_t)r * ocols + ocols - 1) * bb, o);
+      else if (c < ocols) pad_block(codec, etc_strategy, 1, blocks + ((size_t)(orows - 1) * ocols + c) * bb, o);
+      else pad_block(codec, etc_strategy, 2, blocks + ((size_t)(orows - 1) * ocols + ocols - 1) * bb, o);
+    }
+  return 1;
+}
+
+static void encode_any_block(int codec, int etc_strategy, const block4x4_t *b, uint8_t *o) {
+  if (codec == ICO_DXT1) encode_dxt1_block(b, 0, 0, o);
+  else if (codec == ICO_DXT5) { encode_dxt5_alpha(b, o); encode_dxt1_block(b, 0, 1, o + 8); }
+  else encode_etc1_block(b, etc_strategy, o);
+}
+
+/* StoreDownsampledPixels4x4 (pixel4x4.h:152-162): 2x2 averages of src (a decoded 4x4) into quadrant (tr, tc) of dst */
+static void store_downsampled(uint8_t src[16][4], int tr, int tc, block4x4_t *dst) {
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 2; ++c) {
+      int v[4];
+      for (int ch = 0; ch < 4; ++ch)
+        v[ch] = (src[4 * (2 * r) + 2 * c][ch] + src[4 * (2 * r) + 2 * c + 1][ch] + src[4 * (2 * r + 1) + 2 * c][ch] +
+                 src[4 * (2 * r + 1) + 2 * c + 1][ch]) / 4;
+      int p = 4 * (tr + r) + tc + c;
+      dst->px[p].r = v[0]; dst->px[p].g = v[1]; dst->px[p].b = v[2]; dst->alpha[p] = v[3];
+    }
+}
+
+int ico_downsample(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, const uint8_t *blocks,
+                   uint8_t *out) {
+  if (compressor == ICO_COMPRESSOR_PVRTC) return 0;
+  int codec = block_codec(compressor, format);
+  size_t bb = block_bytes(codec);
+  int orows = (int)nblk(uh), ocols = (int)nblk(uw);
+  if ((orows > 1 && orows % 2) || (ocols > 1 && ocols % 2)) return 0; /* helper.h:281-284 */
+  int drows = orows / 2, dcols = ocols / 2;
+  uint8_t px[16][4];
+  block4x4_t b;
+  b.one_pixel = 0;
+  if (orows > 1 && ocols > 1) {
+    for (int r = 0; r < drows; ++r)
+      for (int c = 0; c < dcols; ++c) {
+        for (int i = 0; i < 2; ++i)
+          for (int j = 0; j < 2; ++j) {
+            decode_block(codec, 0, blocks + ((size_t)(2 * r + i) * ocols + 2 * c + j) * bb, px);
+            store_downsampled(px, 2 * i, 2 * j, &b);
+          }
+        encode_any_block(codec, etc_strategy, &b, out + ((size_t)r * dcols + c) * bb);
+      }
+  } else if (orows > 1) { /* one block column: each source block fills two quadrant columns */
+    for (int r = 0; r < drows; ++r) {
+      for (int i = 0; i < 2; ++i) {
+        decode_block(codec, 0, blocks + (size_t)(2 * r + i) * bb, px);
+        store_downsampled(px, 2 * i, 0, &b);
+        store_downsampled(px, 2 * i, 2, &b);
+      }
+      encode_any_block(codec, etc_strategy, &b, out + (size_t)r * bb);
+    }
+  } else if (ocols > 1) {
+    for (int c = 0; c < dcols; ++c) {
+      for (int j = 0; j < 2; ++j) {
+        decode_block(codec, 0, blocks + (size_t)(2 * c + j) * bb, px);
+        store_downsampled(px, 0, 2 * j, &b);
+        store_downsampled(px, 2, 2 * j, &b);
+      }
+      encode_any_block(codec, etc_strategy, &b, out + (size_t)c * bb);
+    }
+  } else { /* a single block: replicate up to 4x4 first (helper.h:338-387) */
+    if (uh == 3 || uw == 3) return 0;
+    decode_block(codec, 0, blocks, px);
+    if (uw == 1) for (int r = 0; r < 4; ++r) for (int x = 1; x < 4; ++x) memcpy(px[4 * r + x], px[4 * r], 4);
+    else if (uw == 2) for (int r = 0; r < 4; ++r) { memcpy(px[4 * r + 2], px[4 * r], 4); memcpy(px[4 * r + 3], px[4 * r + 1], 4); }
+    if (uh == 1) for (int c = 0; c < 4; ++c) for (int y = 1; y < 4; ++y) memcpy(px[4 * y + c], px[c], 4);
+    else if (uh == 2) for (int c = 0; c < 4; ++c) { memcpy(px[8 + c], px[c], 4); memcpy(px[12 + c], px[4 + c], 4); }
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c) store_downsampled(px, 2 * r, 2 * c, &b);
+    encode_any_block(codec, etc_strategy, &b, out);
+  }
+  return 1;
+}
+
+void ico_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes) {
+  for (size_t i = 0; i + 8 <= n_bytes; i += 8) {
+    uint8_t px[16][4];
+    block4x4_t b;
+    decode_block(ICO_DXT1, 0, blocks + i, px);
+    b.one_pixel = 0;
+    for (int p = 0; p < 16; ++p) { b.px[p].r = px[p][0]; b.px[p].g = px[p][1]; b.px[p].b = px[p][2]; b.alpha[p] = 255; }
+    encode_etc1_block(&b, ICO_ETC_HEURISTIC, blocks + i);
+  }
+}

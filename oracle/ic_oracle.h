@@ -69,6 +69,32 @@ size_t ico_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width);
 int ico_decode(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                const uint8_t *blocks, uint8_t *out);
 
+/* ---- compressed-domain operations ----
+ * All take the block grid of an image whose metadata says compressed dims (ch, cw) / uncompressed dims (uh, uw).
+ * Return 1/0 like the reference's bool; *out_h / *out_w receive the result's uncompressed dims. */
+
+/* Compressor::CreateSolidImage (dxtc.cc:820-839, etc.cc:801-811, helper.h:522-543): `out` gets
+ * ico_compute_compressed_data_size(compressor, format, h, w) bytes. */
+int ico_create_solid(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color, uint8_t *out);
+
+/* Compressor::CopySubimage (helper.h:545-592). */
+int ico_copy_subimage(int compressor, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks,
+                      uint32_t start_row, uint32_t start_col, uint32_t height, uint32_t width, uint8_t *out);
+
+/* Compressor::Pad (helper.h:393-477; pad functors dxtc.cc:594-696, etc.cc:645-698).  Returns 2 when the
+ * reference only duplicates the image (both padded dims <= compressed dims).  Refuses (0) the case where exactly
+ * one padded dimension is smaller than the compressed one: the reference writes out of bounds there. */
+int ico_pad(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks,
+            uint32_t padded_height, uint32_t padded_width, uint8_t *out);
+
+/* Compressor::Downsample (helper.h:264-391,594-636): decodes 2x2 / 2x1 / 1x2 / 1 block(s), averages 2x2 pixels
+ * (cutil.h:335-380), re-encodes.  out holds blocks for ((uh+1)/2, (uw+1)/2). */
+int ico_downsample(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, const uint8_t *blocks,
+                   uint8_t *out);
+
+/* TranscodeDxt1ToEtc1 (dxtc_to_etc_transcoder.cc:29-40): in place, n_bytes of DXT1 blocks -> ETC1 (kHeuristic). */
+void ico_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include "image_compression/public/compressed_image.h"
 #include "image_compression/public/compressor.h"
 #include "image_compression/public/dxtc_compressor.h"
+#include "image_compression/public/dxtc_to_etc_transcoder.h"
 #include "image_compression/public/etc_compressor.h"
 #include "image_compression/public/pvrtc_compressor.h"
 
@@ -93,6 +94,32 @@ static void RunCompressor(Compressor *c, const char *cname, bool is_pvrtc) {
           }
         }
       }
+      if (pad == 0) {  // compressed-domain operations on the image just produced
+        CompressedImage src;
+        if (c->Compress(fmt, h, w, 0, img.data(), &src)) {
+          const uint32 ch = src.GetMetadata().compressed_height, cw = src.GetMetadata().compressed_width;
+          CompressedImage down;
+          std::snprintf(name, sizeof name, "%s Downsample fmt=%d %ux%u", cname, f, h, w);
+          Report(name, c->Downsample(src, &down), down);
+          const uint32 pads[4][2] = { { ch + 4, cw + 8 }, { h, w }, { ch + 1, cw }, { ch, cw + 13 } };
+          for (int k = 0; k < 4; ++k) {
+            CompressedImage padded;
+            std::snprintf(name, sizeof name, "%s Pad fmt=%d %ux%u -> %ux%u", cname, f, h, w, pads[k][0], pads[k][1]);
+            Report(name, c->Pad(src, pads[k][0], pads[k][1], &padded), padded);
+          }
+          const uint32 subs[4][4] = { { 0, 0, ch, cw }, { 4, 4, 4, 4 }, { 0, 4, 8, 4 }, { 2, 0, 4, 4 } };
+          for (int k = 0; k < 4; ++k) {
+            CompressedImage sub;
+            std::snprintf(name, sizeof name, "%s CopySubimage fmt=%d %ux%u @%u,%u %ux%u", cname, f, h, w, subs[k][0],
+                          subs[k][1], subs[k][2], subs[k][3]);
+            Report(name, c->CopySubimage(src, subs[k][0], subs[k][1], subs[k][2], subs[k][3], &sub), sub);
+          }
+        }
+        const uint8 color[4] = { (uint8)(200 + f), (uint8)(100 + s), 50, (uint8)(17 * s) };
+        CompressedImage solid;
+        std::snprintf(name, sizeof name, "%s CreateSolidImage fmt=%d %ux%u", cname, f, h, w);
+        Report(name, c->CreateSolidImage(fmt, h, w, color, &solid), solid);
+      }
       {  // external storage: exact size, then wrong size
         size_t n = c->ComputeCompressedDataSize(fmt, h, w);
         std::vector<uint8> store(n + 16, 0x11);
@@ -129,6 +156,19 @@ static void RunCompressor(Compressor *c, const char *cname, bool is_pvrtc) {
 int main() {
   DxtcCompressor dxtc;
   RunCompressor(&dxtc, "dxtc", false);
+  {  // DXT1 -> ETC1 transcoder
+    const uint32 shapes[3][2] = { { 64, 64 }, { 13, 7 }, { 128, 32 } };
+    for (int s = 0; s < 3; ++s) {
+      std::vector<uint8> img = MakeImage(shapes[s][0], shapes[s][1], 3, 0, 900 + s);
+      CompressedImage out;
+      if (dxtc.Compress(CompressedImage::kRGB, shapes[s][0], shapes[s][1], 0, img.data(), &out)) {
+        TranscodeDxt1ToEtc1(&out);
+        char nm[96];
+        std::snprintf(nm, sizeof nm, "transcode dxt1->etc1 %ux%u", shapes[s][0], shapes[s][1]);
+        Report(nm, true, out);
+      }
+    }
+  }
   EtcCompressor etc;
   std::printf("etc default strategy=%d\n", (int)etc.GetCompressionStrategy());
   const EtcCompressor::CompressionStrategy strategies[4] = { EtcCompressor::kSplitHorizontally,

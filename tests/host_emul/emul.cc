@@ -13,6 +13,7 @@
 #include "etc1_block.h"
 #include "pvrtc_block.h"
 #include "decode_block.h"
+#include "blockops_block.h"
 
 using namespace icamd;
 
@@ -60,4 +61,82 @@ extern "C" int emul_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t
           memcpy(out + (br * 4 + y) * stride + (size_t)(bc * 4 + x) * comps, &px[4 * y + x], comps);
     }
   return 1;
+}
+
+// ---- compressed-domain operations through the device per-block math (blockops_block.h)
+template <int CODEC>
+static void emul_pad_t(int strategy, uint32_t orows, uint32_t ocols, uint32_t prows, uint32_t pcols, const uint8_t *in, uint8_t *out) {
+  const int W = CODEC == 1 ? 4 : 2;
+  for (uint32_t r = 0; r < prows; ++r)
+    for (uint32_t c = 0; c < pcols; ++c) {
+      const bool in_rows = r < orows, in_cols = c < ocols;
+      const uint32_t *s = reinterpret_cast<const uint32_t *>(in) + ((size_t)(in_rows ? r : orows - 1) * ocols + (in_cols ? c : ocols - 1)) * W;
+      uint32_t *d = reinterpret_cast<uint32_t *>(out) + ((size_t)r * pcols + c) * W;
+      if (in_rows && in_cols) { memcpy(d, s, W * 4); continue; }
+      const int kind = in_rows ? kPadColumn : (in_cols ? kPadRow : kPadCorner);
+      if (CODEC == 2) { Out8 o = etc1_pad_block(s[0], s[1], kind, (uint32_t)strategy); d[0] = o.lo; d[1] = o.hi; }
+      else if (CODEC == 0) { d[0] = s[0]; d[1] = dxt_pad_color_bits(s[1], kind); }
+      else {
+        uint32_t lo24 = s[0] >> 16 | (s[1] & 0xffu) << 16, hi24 = s[1] >> 8;
+        dxt5_pad_alpha_codes(lo24, hi24, kind);
+        d[0] = (s[0] & 0xffffu) | lo24 << 16; d[1] = lo24 >> 16 | hi24 << 8; d[2] = s[2]; d[3] = dxt_pad_color_bits(s[3], kind);
+      }
+    }
+}
+extern "C" int emul_pad(int codec, int strategy, uint32_t ch, uint32_t cw, uint32_t ph, uint32_t pw, const uint8_t *in, uint8_t *out) {
+  const uint32_t orows = (ch + 3) / 4, ocols = (cw + 3) / 4, prows = (ph + 3) / 4, pcols = (pw + 3) / 4;
+  if (prows < orows || pcols < ocols) return 0;
+  if (codec == 0) emul_pad_t<0>(strategy, orows, ocols, prows, pcols, in, out);
+  else if (codec == 1) emul_pad_t<1>(strategy, orows, ocols, prows, pcols, in, out);
+  else emul_pad_t<2>(strategy, orows, ocols, prows, pcols, in, out);
+  return 1;
+}
+
+template <int CODEC>
+static int emul_downsample_t(int strategy, uint32_t uh, uint32_t uw, const uint8_t *in, uint8_t *out) {
+  const int W = CODEC == 1 ? 4 : 2;
+  const uint32_t orows = (uh + 3) / 4, ocols = (uw + 3) / 4;
+  if ((orows > 1 && orows % 2) || (ocols > 1 && ocols % 2)) return 0;
+  if (orows == 1 && ocols == 1 && (uh == 3 || uw == 3)) return 0;
+  const uint32_t drows = ((uh + 1) / 2 + 3) / 4, dcols = ((uw + 1) / 2 + 3) / 4;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(in);
+  for (uint32_t r = 0; r < drows; ++r)
+    for (uint32_t c = 0; c < dcols; ++c) {
+      uint32_t px[16], tmp[16];
+      if (orows > 1 && ocols > 1) {
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+          decode_any<CODEC>(src + ((size_t)(2 * r + i) * ocols + 2 * c + j) * W, tmp);
+          store_downsampled(tmp, 2 * i, 2 * j, px);
+        }
+      } else if (orows > 1) {
+        for (int i = 0; i < 2; ++i) { decode_any<CODEC>(src + (size_t)(2 * r + i) * W, tmp); store_downsampled(tmp, 2 * i, 0, px); store_downsampled(tmp, 2 * i, 2, px); }
+      } else if (ocols > 1) {
+        for (int j = 0; j < 2; ++j) { decode_any<CODEC>(src + (size_t)(2 * c + j) * W, tmp); store_downsampled(tmp, 0, 2 * j, px); store_downsampled(tmp, 2, 2 * j, px); }
+      } else {
+        decode_any<CODEC>(src, tmp);
+        if (uw == 1) for (int y = 0; y < 4; ++y) tmp[4 * y + 1] = tmp[4 * y + 2] = tmp[4 * y + 3] = tmp[4 * y];
+        else if (uw == 2) for (int y = 0; y < 4; ++y) { tmp[4 * y + 2] = tmp[4 * y]; tmp[4 * y + 3] = tmp[4 * y + 1]; }
+        if (uh == 1) for (int x = 0; x < 4; ++x) tmp[4 + x] = tmp[8 + x] = tmp[12 + x] = tmp[x];
+        else if (uh == 2) for (int x = 0; x < 4; ++x) { tmp[8 + x] = tmp[x]; tmp[12 + x] = tmp[4 + x]; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) store_downsampled(tmp, 2 * i, 2 * j, px);
+      }
+      BlockStash stash;
+      uint32_t o[4];
+      encode_any<CODEC>(px, (uint32_t)strategy, stash, o);
+      memcpy(reinterpret_cast<uint32_t *>(out) + ((size_t)r * dcols + c) * W, o, W * 4);
+    }
+  return 1;
+}
+extern "C" int emul_downsample(int codec, int strategy, uint32_t uh, uint32_t uw, const uint8_t *in, uint8_t *out) {
+  if (codec == 0) return emul_downsample_t<0>(strategy, uh, uw, in, out);
+  if (codec == 1) return emul_downsample_t<1>(strategy, uh, uw, in, out);
+  return emul_downsample_t<2>(strategy, uh, uw, in, out);
+}
+extern "C" void emul_transcode(uint8_t *blocks, size_t n_bytes) {
+  for (size_t i = 0; i + 8 <= n_bytes; i += 8) {
+    uint32_t *b = reinterpret_cast<uint32_t *>(blocks + i), px[16];
+    decode_dxt_colors(b[0], b[1], false, false, px);
+    Out8 o = encode_etc1_block(px, 3u);
+    b[0] = o.lo; b[1] = o.hi;
+  }
 }

@@ -237,3 +237,135 @@ def with_row_padding(img, pad):
         return np.ascontiguousarray(flat).reshape(-1)
     junk = np.full((h, pad), 0xA5, np.uint8)
     return np.ascontiguousarray(np.concatenate([flat, junk], axis=1)).reshape(-1)
+
+
+# ------------------------------------------- compressed-domain operations
+
+def _bind_ops():
+    L = oracle()
+    if getattr(L, "_ops_bound", False):
+        return L
+    L.ico_create_solid.restype = ci
+    L.ico_create_solid.argtypes = [ci, ci, u32, u32, vp, vp]
+    L.ico_copy_subimage.restype = ci
+    L.ico_copy_subimage.argtypes = [ci, ci, u32, u32, vp, u32, u32, u32, u32, vp]
+    L.ico_pad.restype = ci
+    L.ico_pad.argtypes = [ci, ci, ci, u32, u32, vp, u32, u32, vp]
+    L.ico_downsample.restype = ci
+    L.ico_downsample.argtypes = [ci, ci, ci, u32, u32, vp, vp]
+    L.ico_transcode_dxt1_to_etc1.restype = None
+    L.ico_transcode_dxt1_to_etc1.argtypes = [vp, sz]
+    L._ops_bound = True
+    return L
+
+
+def _bind_ref_ops():
+    L = ref()
+    if getattr(L, "_ops_bound", False):
+        return L
+    L.ref_create_solid.restype = ci
+    L.ref_create_solid.argtypes = [ci, ci, u32, u32, vp, vp, sz]
+    L.ref_pad.restype = ci
+    L.ref_pad.argtypes = [ci, ci, ci, u32, u32, u32, u32, vp, sz, u32, u32, vp, sz, vp, vp]
+    L.ref_downsample.restype = ci
+    L.ref_downsample.argtypes = [ci, ci, ci, u32, u32, u32, u32, vp, sz, vp, sz, vp, vp]
+    L.ref_copy_subimage.restype = ci
+    L.ref_copy_subimage.argtypes = [ci, ci, u32, u32, u32, u32, vp, sz, u32, u32, u32, u32, vp, sz, vp, vp]
+    L.ref_transcode_dxt1_to_etc1.restype = None
+    L.ref_transcode_dxt1_to_etc1.argtypes = [u32, u32, u32, u32, vp, sz]
+    L._ops_bound = True
+    return L
+
+
+def _b4(n):
+    return 4 * ((n + 3) // 4)
+
+
+def oracle_create_solid(compressor, fmt, h, w, color):
+    n = ((h + 3) // 4) * ((w + 3) // 4) * (8 if (compressor == ETC or comps_of(fmt) == 3) else 16)
+    out = np.zeros(max(n, 1), np.uint8)
+    c = np.asarray(color, np.uint8)
+    ok = _bind_ops().ico_create_solid(compressor, fmt, h, w, _ptr(c), _ptr(out))
+    return out[:n].tobytes() if ok else None
+
+
+def ref_create_solid(compressor, fmt, h, w, color):
+    n = ((h + 3) // 4) * ((w + 3) // 4) * (8 if (compressor == ETC or comps_of(fmt) == 3) else 16)
+    out = np.zeros(max(n, 1), np.uint8)
+    c = np.asarray(color, np.uint8)
+    ok = _bind_ref_ops().ref_create_solid(compressor, fmt, h, w, _ptr(c), _ptr(out), n)
+    return out[:n].tobytes() if ok else None
+
+
+def oracle_copy_subimage(compressor, fmt, blocks, ch, cw, row, col, h, w):
+    bb = 8 if (compressor == ETC or comps_of(fmt) == 3) else 16
+    n = ((h + 3) // 4) * ((w + 3) // 4) * bb
+    out = np.zeros(max(n, 1), np.uint8)
+    b = np.frombuffer(blocks, np.uint8)
+    ok = _bind_ops().ico_copy_subimage(compressor, fmt, ch, cw, _ptr(b), row, col, h, w, _ptr(out))
+    return out[:n].tobytes() if ok else None
+
+
+def ref_copy_subimage(compressor, fmt, blocks, uh, uw, row, col, h, w):
+    b = np.frombuffer(blocks, np.uint8).copy()
+    out = np.zeros(b.size + 64, np.uint8)
+    n = sz(0)
+    ok = _bind_ref_ops().ref_copy_subimage(compressor, fmt, uh, uw, _b4(uh), _b4(uw), _ptr(b), b.size, row, col, h, w,
+                                           _ptr(out), out.size, ctypes.byref(n), None)
+    return out[:n.value].tobytes() if ok else None
+
+
+def oracle_pad(compressor, fmt, blocks, ch, cw, ph, pw, strategy=SMALLER_ERROR):
+    bb = 8 if (compressor == ETC or comps_of(fmt) == 3) else 16
+    cap = max(((max(ph, ch) + 3) // 4) * ((max(pw, cw) + 3) // 4) * bb, len(blocks)) + 64
+    out = np.zeros(cap, np.uint8)
+    b = np.frombuffer(blocks, np.uint8)
+    rc = _bind_ops().ico_pad(compressor, strategy, fmt, ch, cw, _ptr(b), ph, pw, _ptr(out))
+    if rc == 0:
+        return None
+    n = len(blocks) if rc == 2 else ((ph + 3) // 4) * ((pw + 3) // 4) * bb
+    return out[:n].tobytes()
+
+
+def ref_pad(compressor, fmt, blocks, uh, uw, ph, pw, strategy=SMALLER_ERROR):
+    b = np.frombuffer(blocks, np.uint8).copy()
+    bb = 8 if (compressor == ETC or comps_of(fmt) == 3) else 16
+    cap = max(((max(ph, uh) + 3) // 4) * ((max(pw, uw) + 3) // 4) * bb, b.size) + 64
+    out = np.zeros(cap, np.uint8)
+    n = sz(0)
+    meta = (u32 * 5)()
+    ok = _bind_ref_ops().ref_pad(compressor, strategy, fmt, uh, uw, _b4(uh), _b4(uw), _ptr(b), b.size, ph, pw, _ptr(out),
+                                 out.size, ctypes.byref(n), meta)
+    return (out[:n.value].tobytes(), tuple(meta)) if ok else None
+
+
+def oracle_downsample(compressor, fmt, blocks, uh, uw, strategy=SMALLER_ERROR):
+    bb = 8 if (compressor == ETC or comps_of(fmt) == 3) else 16
+    dh, dw = (uh + 1) // 2, (uw + 1) // 2
+    n = ((dh + 3) // 4) * ((dw + 3) // 4) * bb
+    out = np.zeros(max(n, 1), np.uint8)
+    b = np.frombuffer(blocks, np.uint8)
+    ok = _bind_ops().ico_downsample(compressor, strategy, fmt, uh, uw, _ptr(b), _ptr(out))
+    return out[:n].tobytes() if ok else None
+
+
+def ref_downsample(compressor, fmt, blocks, uh, uw, strategy=SMALLER_ERROR):
+    b = np.frombuffer(blocks, np.uint8).copy()
+    out = np.zeros(b.size + 64, np.uint8)
+    n = sz(0)
+    meta = (u32 * 5)()
+    ok = _bind_ref_ops().ref_downsample(compressor, strategy, fmt, uh, uw, _b4(uh), _b4(uw), _ptr(b), b.size, _ptr(out),
+                                        out.size, ctypes.byref(n), meta)
+    return (out[:n.value].tobytes(), tuple(meta)) if ok else None
+
+
+def oracle_transcode(blocks):
+    b = np.frombuffer(blocks, np.uint8).copy()
+    _bind_ops().ico_transcode_dxt1_to_etc1(_ptr(b), b.size)
+    return b.tobytes()
+
+
+def ref_transcode(blocks, uh, uw):
+    b = np.frombuffer(blocks, np.uint8).copy()
+    _bind_ref_ops().ref_transcode_dxt1_to_etc1(uh, uw, _b4(uh), _b4(uw), _ptr(b), b.size)
+    return b.tobytes()

@@ -241,3 +241,58 @@ def test_pvrtc_call_sequences_host_api(pkg):
     for n in (64, 8, 128, 16, 256, 128, 8, 512, 128):
         img = T.s_mixed(n, n, 4, index=n + 1)
         assert pkg.compress_host(T.PVRTC, T.RGBA, img.reshape(-1), n, n) == T.oracle_encode(T.PVRTC2, img, n, n, 4), n
+
+
+def test_slab_sharding_of_one_image_on_device(pkg):
+    # one large DXT/ETC image split into block-row slabs (what each rank of an N-GPU job encodes);
+    # here the "ranks" run one after the other on the single GPU and their byte ranges must tile the whole output.
+    import torch
+    from image_compression_amd import sharding
+    h, w, pad = 1022, 515, 3
+    for codec, comps, bb in ((T.DXT1, 3, 8), (T.DXT5, 4, 16), (T.ETC1, 3, 8)):
+        img = T.s_mixed(h, w, comps, index=21)
+        src = T.with_row_padding(img, pad)
+        stride = w * comps + pad
+        d = _dev(src)
+        whole = _host(pkg.encode_device(codec, d, h, w, comps, row_stride_bytes=stride))
+        assert whole == T.oracle_encode(codec, src, h, w, comps, stride=stride, threads=8)
+        for world in (2, 3, 8):
+            parts = []
+            for rank in range(world):
+                g = sharding.slab_geometry(h, w, comps, stride, bb, world, rank)
+                slab = d[g["src_offset_bytes"]:].contiguous()
+                out = pkg.encode_device(codec, slab, g["pixel_rows"], w, comps, row_stride_bytes=stride,
+                                        grid_height=g["block_rows"] * 4, grid_width=w)
+                torch.cuda.synchronize()
+                parts.append(out.cpu().numpy().tobytes())
+                assert len(parts[-1]) == g["dst_bytes"]
+            assert b"".join(parts) == whole, (codec, world)
+
+
+# ---- "next" rows 8f.2-4: Pad / Downsample / DXT1->ETC1 transcode kernels
+
+def test_blockops_match_oracle(pkg):
+    for compressor, fmt, strategy in [(T.DXTC, T.RGB, 2), (T.DXTC, T.BGR, 2), (T.DXTC, T.RGBA, 2), (T.ETC, T.RGB, 0),
+                                      (T.ETC, T.RGB, 2), (T.ETC, T.RGB, 3)]:
+        for (h, w) in [(256, 512), (32, 48), (13, 7), (64, 8), (8, 64), (4, 4), (2, 2), (1, 4), (3, 8)]:
+            img = T.s_mixed(h, w, T.comps_of(fmt), index=h + w)
+            blocks = T.oracle_compress(compressor, fmt, img, h, w, 0, strategy)
+            ch, cw = 4 * ((h + 3) // 4), 4 * ((w + 3) // 4)
+            for (ph, pw) in [(h + 9, w + 5), (ch, cw + 8), (ch + 4, cw)]:
+                assert pkg.pad_host(compressor, fmt, blocks, ch, cw, ph, pw, strategy) == \
+                    T.oracle_pad(compressor, fmt, blocks, ch, cw, ph, pw, strategy), (compressor, fmt, h, w, ph, pw)
+            assert pkg.downsample_host(compressor, fmt, blocks, h, w, strategy) == \
+                T.oracle_downsample(compressor, fmt, blocks, h, w, strategy), (compressor, fmt, h, w)
+    # a mip chain entirely in the compressed domain: 1024 -> 512 -> ... -> 4
+    img = T.s_smooth(1024, 1024, 3, index=2)
+    cur = T.oracle_compress(T.DXTC, T.RGB, img, 1024, 1024)
+    n = 1024
+    while n > 4:
+        nxt = pkg.downsample_host(T.DXTC, T.RGB, cur, n, n)
+        assert nxt == T.oracle_downsample(T.DXTC, T.RGB, cur, n, n), n
+        cur, n = nxt, n // 2
+    g = np.random.Generator(np.random.PCG64(3))
+    raw = g.integers(0, 256, size=8 * 65536, dtype=np.uint8).tobytes()
+    assert pkg.transcode_dxt1_to_etc1_host(raw) == T.oracle_transcode(raw)
+    enc = T.oracle_compress(T.DXTC, T.RGB, T.s_mixed(512, 512, 3, index=4), 512, 512)
+    assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)

@@ -120,3 +120,34 @@ def test_decode_math_matches_oracle(emul):
                     bb = np.frombuffer(blocks, np.uint8)
                     assert emul.emul_decode(codec, swap, h, w, pad, bb.ctypes.data, out.ctypes.data)
                     assert np.array_equal(out, want), (codec, swap, h, w, pad, kind)
+
+
+def test_blockops_math_matches_oracle(emul):
+    emul.emul_pad.restype = ctypes.c_int
+    emul.emul_pad.argtypes = [T.ci, T.ci, T.u32, T.u32, T.u32, T.u32, T.vp, T.vp]
+    emul.emul_downsample.restype = ctypes.c_int
+    emul.emul_downsample.argtypes = [T.ci, T.ci, T.u32, T.u32, T.vp, T.vp]
+    emul.emul_transcode.restype = None
+    emul.emul_transcode.argtypes = [T.vp, T.sz]
+    for compressor, fmt, codec, strategy in [(T.DXTC, T.RGB, T.DXT1, 2), (T.DXTC, T.BGRA, T.DXT5, 2), (T.ETC, T.RGB, T.ETC1, 0),
+                                            (T.ETC, T.RGB, T.ETC1, 2), (T.ETC, T.RGB, T.ETC1, 3)]:
+        bb = 16 if codec == T.DXT5 else 8
+        for (h, w) in [(32, 48), (13, 7), (64, 8), (8, 64), (4, 4), (2, 2), (1, 4), (4, 1), (3, 8), (16, 16)]:
+            img = T.s_mixed(h, w, T.comps_of(fmt), index=h + w)
+            blocks = T.oracle_compress(compressor, fmt, img, h, w, 0, strategy)
+            b = np.frombuffer(blocks, np.uint8)
+            ch, cw = 4 * ((h + 3) // 4), 4 * ((w + 3) // 4)
+            for (ph, pw) in [(h + 9, w + 5), (ch, cw + 8), (ch + 4, cw)]:
+                want = T.oracle_pad(compressor, fmt, blocks, ch, cw, ph, pw, strategy)
+                out = np.zeros(((ph + 3) // 4) * ((pw + 3) // 4) * bb, np.uint8)
+                assert emul.emul_pad(codec, strategy, ch, cw, ph, pw, b.ctypes.data, out.ctypes.data)
+                assert out.tobytes() == want, (codec, h, w, ph, pw)
+            want = T.oracle_downsample(compressor, fmt, blocks, h, w, strategy)
+            out = np.zeros(max(len(want) if want else 0, bb), np.uint8)
+            ok = emul.emul_downsample(codec, strategy, h, w, b.ctypes.data, out.ctypes.data)
+            assert (out[:len(want)].tobytes() if ok else None) == want, (codec, h, w)
+    g = np.random.Generator(np.random.PCG64(3))
+    raw = g.integers(0, 256, size=8 * 2048, dtype=np.uint8)
+    want = T.oracle_transcode(raw.tobytes())
+    emul.emul_transcode(raw.ctypes.data, raw.size)
+    assert raw.tobytes() == want

@@ -120,3 +120,44 @@ def test_decoders_match():
     assert np.array_equal(T.ref_decompress(T.DXTC, T.RGB, blocks, 64, 64), T.oracle_decode(T.DXT1, blocks, 64, 64))
     blocks = g.integers(0, 256, size=64 * 64 // 16 * 16, dtype=np.uint8).tobytes()
     assert np.array_equal(T.ref_decompress(T.DXTC, T.RGBA, blocks, 64, 64), T.oracle_decode(T.DXT5, blocks, 64, 64))
+
+
+# ---- compressed-domain operations
+
+OPS_CASES = [(T.DXTC, T.RGB, 2), (T.DXTC, T.BGR, 2), (T.DXTC, T.RGBA, 2), (T.DXTC, T.BGRA, 2), (T.ETC, T.RGB, 0),
+             (T.ETC, T.RGB, 2), (T.ETC, T.RGB, 3)]
+
+
+@pytest.mark.parametrize("compressor,fmt,strategy", OPS_CASES)
+def test_pad_downsample_subimage_match(compressor, fmt, strategy):
+    for (h, w) in [(32, 48), (13, 7), (64, 8), (8, 64), (4, 4), (2, 2), (1, 4), (4, 1), (16, 4), (4, 16), (3, 8)]:
+        img = T.s_mixed(h, w, T.comps_of(fmt), index=h + w)
+        blocks = T.ref_compress(compressor, fmt, img, h, w, 0, strategy)
+        ch, cw = 4 * ((h + 3) // 4), 4 * ((w + 3) // 4)
+        for (ph, pw) in [(h + 9, w + 5), (ch, cw + 8), (ch + 4, cw), (h, w), (ch + 1, cw + 1)]:
+            a = T.ref_pad(compressor, fmt, blocks, h, w, ph, pw, strategy)
+            b = T.oracle_pad(compressor, fmt, blocks, ch, cw, ph, pw, strategy)
+            assert a is not None and a[0] == b, (h, w, ph, pw)
+        a = T.ref_downsample(compressor, fmt, blocks, h, w, strategy)
+        b = T.oracle_downsample(compressor, fmt, blocks, h, w, strategy)
+        assert (a[0] if a else None) == b, (h, w)
+        for (r, c, sh, sw) in [(0, 0, ch, cw), (4, 4, 4, 4), (0, 4, 8, 4), (4, 0, 4, 8), (2, 0, 4, 4), (0, 0, ch + 4, 4)]:
+            a = T.ref_copy_subimage(compressor, fmt, blocks, h, w, r, c, sh, sw)
+            b = T.oracle_copy_subimage(compressor, fmt, blocks, ch, cw, r, c, sh, sw)
+            assert a == b, (h, w, r, c, sh, sw)
+
+
+def test_solid_and_transcode_match():
+    for compressor in (T.DXTC, T.ETC, T.PVRTC):
+        for fmt in (T.RGB, T.BGR, T.RGBA, T.BGRA):
+            for color in [(200, 100, 50, 77), (0, 0, 0, 0), (255, 255, 255, 255), (1, 2, 3, 4), (129, 7, 250, 128)]:
+                for (h, w) in [(8, 12), (5, 3), (1, 1)]:
+                    assert T.ref_create_solid(compressor, fmt, h, w, color) == T.oracle_create_solid(compressor, fmt, h, w, color)
+    for (h, w) in [(64, 64), (13, 7)]:
+        for gen in ("noise", "smooth", "flat", "mixed"):
+            img = T.GENERATORS[gen](h, w, 3, index=9)
+            blocks = T.ref_compress(T.DXTC, T.RGB, img, h, w)
+            assert T.ref_transcode(blocks, h, w) == T.oracle_transcode(blocks)
+    g = np.random.Generator(np.random.PCG64(3))
+    raw = g.integers(0, 256, size=8 * 4096, dtype=np.uint8).tobytes()  # arbitrary DXT1 blocks (3-colour mode etc.)
+    assert T.ref_transcode(raw, 256, 256) == T.oracle_transcode(raw)
