@@ -103,12 +103,11 @@ ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 ICAMD_DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 // v_dot4_u32_u8: a.b0*b.b0 + a.b1*b.b1 + a.b2*b.b2 + a.b3*b.b3 + c
 ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
-// v_sad_u32: |a - b| + c
-ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t d;
-  asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
+// |a - b| + c for 16-bit operands
+// PRECONDITION a, b < 65536.  Emitted as v_sad_u16 (|a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c; the high halves
+// are both zero), which has a compiler builtin; v_sad_u32 only exists as inline asm, and every asm statement costs
+// hazard s_nops and blocks scheduling.
+ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
 // v_sad_u8: sum over the 4 bytes of |a.b - b.b|, plus c
 ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
 // v_alignbit_b32: low 32 bits of ({hi,lo} >> sh)

@@ -154,18 +154,6 @@ ICAMD_DEV uint32_t pvrtc_pixel_mod(uint32_t pixel, const PvrtcAB nb[3][3]) {
                          bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw));
 }
 
-// v_add_u32 / v_sub_u32 run at twice the rate of shifts-left, multiplies and 3-operand ops on gfx950
-// (measured: scripts/ubench_valu.hip), so doubling is spelled as an add the compiler may not turn into a shift.
-#if defined(ICAMD_HOST_EMULATION)
-ICAMD_DEV uint32_t add_fr(uint32_t a, uint32_t b) { return a + b; }
-#else
-ICAMD_DEV uint32_t add_fr(uint32_t a, uint32_t b) {
-  uint32_t d;
-  asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-#endif
-ICAMD_DEV uint32_t times2(uint32_t a) { return add_fr(a, a); }
 // Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
@@ -178,8 +166,8 @@ ICAMD_DEV uint32_t opaque(uint32_t v) {
 
 // (4-yw)*top + yw*bot on a channel pair (both 16-bit lanes; <= 4*255 per lane).
 ICAMD_DEV uint32_t vblend_pair(uint32_t yw, uint32_t top, uint32_t bot) {
-  if (yw == 0u) return times2(times2(top));
-  if (yw == 2u) return times2(top + bot);
+  if (yw == 0u) return top << 2;
+  if (yw == 2u) return (top + bot) << 1;
   return yw == 1u ? 3u * top + bot : top + 3u * bot;
 }
 
@@ -195,8 +183,8 @@ ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t 
   const uint32_t c0 = perm(sa_ga, sa_rb, kSel), c3 = perm(sb_ga, sb_rb, kSel);
   const uint32_t a_rb = sa_rb & 0x00ff00ffu, a_ga = sa_ga & 0x00ff00ffu;
   const uint32_t b_rb = sb_rb & 0x00ff00ffu, b_ga = sb_ga & 0x00ff00ffu;
-  const uint32_t s_rb = times2(times2(a_rb + b_rb)), d_rb = a_rb - b_rb;
-  const uint32_t s_ga = times2(times2(a_ga + b_ga)), d_ga = a_ga - b_ga;
+  const uint32_t s_rb = (a_rb + b_rb) << 2, d_rb = a_rb - b_rb;
+  const uint32_t s_ga = (a_ga + b_ga) << 2, d_ga = a_ga - b_ga;
   const uint32_t c1 = perm((s_ga + d_ga) >> 3, (s_rb + d_rb) >> 3, kSel);
   const uint32_t c2 = perm((s_ga - d_ga) >> 3, (s_rb - d_rb) >> 3, kSel);
   const uint32_t d0 = sad_u8(pixel, c0, 0u), d1 = sad_u8(pixel, c1, 0u);
@@ -248,7 +236,7 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const Pvrtc
     for (int v = 0; v < 4; ++v) {
       const uint32_t vl = V[h][v], vr = V[h + 1][v];
       D[v] = vr - vl;
-      P[v] = h == 0 ? times2(times2(vl + vr)) : times2(times2(times2(vl)));
+      P[v] = h == 0 ? (vl + vr) << 2 : vl << 3;
     }
     uint32_t acc = 0;
     ICAMD_UNROLL
@@ -259,7 +247,7 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const Pvrtc
       ICAMD_SCHED_FENCE();
       if (j < 3) {
         ICAMD_UNROLL
-        for (int v = 0; v < 4; ++v) P[v] = add_fr(P[v], D[v]);
+        for (int v = 0; v < 4; ++v) P[v] += D[v];
       }
     }
     row[h] = acc;
@@ -267,7 +255,7 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const Pvrtc
   if (WITH_RIGHT) {
     uint32_t P[4];
     ICAMD_UNROLL
-    for (int v = 0; v < 4; ++v) P[v] = times2(times2(V[1][v] + V[2][v]));
+    for (int v = 0; v < 4; ++v) P[v] = (V[1][v] + V[2][v]) << 2;
     *right_mod = accumulate_mod(right_pixel, P, 1u, 0u);
   }
 }
