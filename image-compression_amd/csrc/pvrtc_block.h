@@ -154,6 +154,18 @@ ICAMD_DEV uint32_t pvrtc_pixel_mod(uint32_t pixel, const PvrtcAB nb[3][3]) {
                          bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw));
 }
 
+// v_pk_lshrrev_b16: logical shift right of both 16-bit lanes
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t pk_lshr16(uint32_t v, uint32_t sh) { return ((v & 0xffffu) >> sh) | ((v >> 16) >> sh) << 16; }
+#else
+typedef unsigned short icamd_pv_us2 __attribute__((ext_vector_type(2)));
+ICAMD_DEV uint32_t pk_lshr16(uint32_t v, uint32_t sh) {
+  const icamd_pv_us2 x = __builtin_bit_cast(icamd_pv_us2, v);
+  const icamd_pv_us2 s = { (unsigned short)sh, (unsigned short)sh };
+  return __builtin_bit_cast(uint32_t, x >> s);
+}
+#endif
+
 // Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
@@ -179,20 +191,17 @@ ICAMD_DEV uint32_t vblend_pair(uint32_t yw, uint32_t top, uint32_t bot) {
 //   "d1 < d0" is the sign of d1 - d0 smeared by an arithmetic shift.
 ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t unit, uint32_t acc) {
   const uint32_t kSel = 0x06020400u;  // bytes: lo.b0, hi.b0, lo.b2, hi.b2  = R, G, B, A
-  const uint32_t sa_rb = P[0] >> 5, sa_ga = P[1] >> 5, sb_rb = P[2] >> 5, sb_ga = P[3] >> 5;
-  const uint32_t c0 = perm(sa_ga, sa_rb, kSel), c3 = perm(sb_ga, sb_rb, kSel);
-  const uint32_t a_rb = sa_rb & 0x00ff00ffu, a_ga = sa_ga & 0x00ff00ffu;
-  const uint32_t b_rb = sb_rb & 0x00ff00ffu, b_ga = sb_ga & 0x00ff00ffu;
+  // per-lane shift (v_pk_lshrrev_b16): clean 8-bit values in both 16-bit lanes, no masking needed
+  const uint32_t a_rb = pk_lshr16(P[0], 5), a_ga = pk_lshr16(P[1], 5), b_rb = pk_lshr16(P[2], 5), b_ga = pk_lshr16(P[3], 5);
+  const uint32_t c0 = perm(a_ga, a_rb, kSel), c3 = perm(b_ga, b_rb, kSel);
   const uint32_t s_rb = (a_rb + b_rb) << 2, d_rb = a_rb - b_rb;
   const uint32_t s_ga = (a_ga + b_ga) << 2, d_ga = a_ga - b_ga;
   const uint32_t c1 = perm((s_ga + d_ga) >> 3, (s_rb + d_rb) >> 3, kSel);
   const uint32_t c2 = perm((s_ga - d_ga) >> 3, (s_rb - d_rb) >> 3, kSel);
   const uint32_t d0 = sad_u8(pixel, c0, 0u), d1 = sad_u8(pixel, c1, 0u);
   const uint32_t d2 = sad_u8(pixel, c2, 0u), d3 = sad_u8(pixel, c3, 0u);
-  const uint32_t t1 = (uint32_t)((int32_t)(d1 - d0) >> 31);
-  const uint32_t t2 = (uint32_t)((int32_t)(d2 - d1) >> 31) & t1;
-  const uint32_t t3 = (uint32_t)((int32_t)(d3 - d2) >> 31) & t2;
-  return acc + (t1 & unit) + (t2 & unit) + (t3 & unit);
+  const bool s1 = d1 < d0, s2 = s1 && d2 < d1, s3 = s2 && d3 < d2;  // stop at the first non-improving step
+  return acc + ((uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3) * unit;
 }
 
 // Scheduling fence: keeps hipcc from interleaving independent pixels / rows, which would multiply the live
