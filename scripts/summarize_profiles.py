@@ -32,6 +32,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     tpath = os.path.join(DST, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    per_step = {}
     for wl in sorted(os.listdir(SRC)):
         d = os.path.join(SRC, wl)
         if not os.path.isdir(d):
@@ -63,7 +64,8 @@ def main():
                 e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2  # gfx950 half-count correction
                 e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
                 e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-                traffic[wl] = int(e["hbm_bytes_per_launch"])
+                steps = 23.0  # bench.py --steps 20 --warmup 3 under the profiler
+                per_step[wl] = per_step.get(wl, 0.0) + e["hbm_bytes_per_launch"] * e.get("calls", steps) / steps
             if "SQ_INSTS_VALU" in e and "SQ_WAVES" in e:
                 e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
         bj = os.path.join(SRC, wl + ".bench.json")
@@ -76,6 +78,8 @@ def main():
             json.dump(summary, f, indent=1, sort_keys=True)
         print(wl, json.dumps({k: {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in e.items()}
                               for k, e in summary["kernels"].items()})[:600])
+    for wl, b in per_step.items():  # bytes per bench step (= per launch for the single-kernel workloads)
+        traffic[wl] = int(b)
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
 
