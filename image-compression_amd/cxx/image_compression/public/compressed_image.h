@@ -1,6 +1,7 @@
-// CompressedImage: the result container of every Compressor call -- a byte buffer (owned by the
-// instance, or borrowed from the caller) plus the metadata needed to interpret it.
-// API-compatible with the reference's image_compression/public/compressed_image.h (:32-204).
+// CompressedImage -- what every Compressor call produces: a byte buffer of encoded blocks plus the metadata needed
+// to interpret it.  The buffer is either owned by the instance (allocated by the compressor) or borrowed from the
+// caller, who then guarantees size and lifetime.  API-compatible with the reference's
+// image_compression/public/compressed_image.h (:32-204): same names, same semantics, same non-copyability.
 #ifndef IMAGE_COMPRESSION_PUBLIC_COMPRESSED_IMAGE_H_
 #define IMAGE_COMPRESSION_PUBLIC_COMPRESSED_IMAGE_H_
 
@@ -16,65 +17,31 @@ namespace image_codec_compression {
 
 class CompressedImage {
  public:
-  // Channel layout of the *uncompressed* pixels.
-  enum Format {
-    kRGB,   // 3 bytes per pixel: R, G, B
-    kBGR,   // 3 bytes per pixel: B, G, R
-    kRGBA,  // 4 bytes per pixel: R, G, B, A
-    kBGRA,  // 4 bytes per pixel: B, G, R, A
-  };
+  // Channel order of the uncompressed pixels.  The numeric values cross the C ABI (include/ic_amd.h).
+  enum Format { kRGB, kBGR, kRGBA, kBGRA };
 
+  // Everything known about the image except its bytes.
   struct Metadata {
-    Metadata(Format format_in, const std::string &compressor_name_in, uint32 uncompressed_height_in,
-             uint32 uncompressed_width_in, uint32 compressed_height_in, uint32 compressed_width_in,
-             uint32 padding_bytes_per_row_in)
-        : format(format_in),
-          compressor_name(compressor_name_in),
-          uncompressed_height(uncompressed_height_in),
-          uncompressed_width(uncompressed_width_in),
-          compressed_height(compressed_height_in),
-          compressed_width(compressed_width_in),
-          padding_bytes_per_row(padding_bytes_per_row_in) {}
-
     Format format;
     std::string compressor_name;   // "dxtc", "etc" or "pvrtc"
-    uint32 uncompressed_height;    // pixels of the source image
+    uint32 uncompressed_height;    // source image, pixels
     uint32 uncompressed_width;
-    uint32 compressed_height;      // pixels covered by the block grid (multiples of the block size)
+    uint32 compressed_height;      // pixels covered by the block grid
     uint32 compressed_width;
-    uint32 padding_bytes_per_row;  // extra bytes per source row; reused when decompressing
+    uint32 padding_bytes_per_row;  // of the source rows; reused by Decompress
+
+    Metadata(Format f, const std::string &name, uint32 uh, uint32 uw, uint32 ch, uint32 cw, uint32 row_padding)
+        : format(f), compressor_name(name), uncompressed_height(uh), uncompressed_width(uw), compressed_height(ch),
+          compressed_width(cw), padding_bytes_per_row(row_padding) {}
   };
 
-  // Empty image that will own whatever a Compressor allocates for it.
-  CompressedImage() : metadata_(kRGB, "", 0, 0, 0, 0, 0), size_(0), bytes_(NULL), owned_(true) {}
+  CompressedImage();                                        // empty; will own what a Compressor allocates
+  CompressedImage(size_t data_size, uint8 *external_data);  // over caller storage; never freed here
+  ~CompressedImage();
 
-  // Image over caller-managed storage: Compressors write into it and never free it.
-  CompressedImage(size_t data_size, uint8 *external_data)
-      : metadata_(kRGB, "", 0, 0, 0, 0, 0), size_(data_size), bytes_(external_data), owned_(false) {}
-
-  ~CompressedImage() {
-    if (owned_) delete[] bytes_;
-  }
-
-  // Deep copy (metadata and bytes); this instance owns the copy afterwards.
-  void Duplicate(const CompressedImage &from) {
-    if (&from == this && owned_) return;
-    const uint8 *src = from.bytes_;
-    CreateOwnedData(from.metadata_, from.size_);
-    std::memcpy(bytes_, src, size_);
-  }
-
-  // Replaces the contents by a freshly allocated, owned buffer of data_size bytes.
-  void CreateOwnedData(const Metadata &metadata, size_t data_size) {
-    if (owned_) delete[] bytes_;
-    metadata_ = metadata;
-    size_ = data_size;
-    bytes_ = new uint8[data_size];
-    owned_ = true;
-  }
-
-  // For instances over external storage.
-  void SetMetadata(const Metadata &metadata) { metadata_ = metadata; }
+  void Duplicate(const CompressedImage &from);                             // deep copy; result is owned
+  void CreateOwnedData(const Metadata &metadata, size_t data_size);        // fresh owned buffer
+  void SetMetadata(const Metadata &metadata) { metadata_ = metadata; }     // for external storage
 
   const Metadata &GetMetadata() const { return metadata_; }
   bool OwnsData() const { return owned_; }
@@ -83,19 +50,47 @@ class CompressedImage {
   uint8 *GetMutableData() { return bytes_; }
 
  private:
-  Metadata metadata_;
-  size_t size_;
-  uint8 *bytes_;
-  bool owned_;
-
-  CompressedImage(const CompressedImage &);  // non-copyable: use Duplicate()
+  CompressedImage(const CompressedImage &);  // use Duplicate()
   void operator=(const CompressedImage &);
+
+  void Release() {
+    if (owned_) delete[] bytes_;
+  }
+
+  Metadata metadata_;
+  uint8 *bytes_;
+  size_t size_;
+  bool owned_;
 };
 
+inline CompressedImage::CompressedImage() : metadata_(kRGB, "", 0, 0, 0, 0, 0), bytes_(NULL), size_(0), owned_(true) {}
+
+inline CompressedImage::CompressedImage(size_t data_size, uint8 *external_data)
+    : metadata_(kRGB, "", 0, 0, 0, 0, 0), bytes_(external_data), size_(data_size), owned_(false) {}
+
+inline CompressedImage::~CompressedImage() { Release(); }
+
+inline void CompressedImage::CreateOwnedData(const Metadata &metadata, size_t data_size) {
+  Release();
+  metadata_ = metadata;
+  bytes_ = new uint8[data_size];
+  size_ = data_size;
+  owned_ = true;
+}
+
+inline void CompressedImage::Duplicate(const CompressedImage &from) {
+  if (&from == this && owned_) return;  // self-copy of owned data: nothing to do
+  const uint8 *source = from.bytes_;    // read before CreateOwnedData may replace it (self-copy of borrowed data)
+  CreateOwnedData(from.metadata_, from.size_);
+  std::memcpy(bytes_, source, size_);
+}
+
 inline int GetNumFormatComponents(CompressedImage::Format format) {
-  return (format == CompressedImage::kRGB || format == CompressedImage::kBGR)     ? 3
-         : (format == CompressedImage::kRGBA || format == CompressedImage::kBGRA) ? 4
-                                                                                   : 0;
+  switch (format) {
+    case CompressedImage::kRGB: case CompressedImage::kBGR: return 3;
+    case CompressedImage::kRGBA: case CompressedImage::kBGRA: return 4;
+  }
+  return 0;
 }
 
 inline bool NeedsRedAndBlueSwapped(CompressedImage::Format format) {

@@ -56,4 +56,24 @@ class Compressor {
 
 }  // namespace image_codec_compression
 
+// Every concrete compressor overrides the same ten methods; the class headers expand this list instead of
+// repeating it.
+#define ICAMD_DECLARE_COMPRESSOR_OVERRIDES()                                                                          \
+  virtual bool SupportsFormat(CompressedImage::Format format) const;                                                  \
+  virtual bool IsValidCompressedImage(const CompressedImage &image);                                                  \
+  virtual size_t ComputeCompressedDataSize(CompressedImage::Format format, uint32 height, uint32 width);              \
+  virtual bool Compress(CompressedImage::Format format, uint32 height, uint32 width, uint32 padding_bytes_per_row,    \
+                        const uint8 *buffer, CompressedImage *image);                                                 \
+  virtual bool Decompress(const CompressedImage &image, std::vector<uint8> *decompressed_buffer);                     \
+  virtual bool Downsample(const CompressedImage &image, CompressedImage *downsampled_image);                          \
+  virtual bool Pad(const CompressedImage &image, uint32 padded_height, uint32 padded_width,                           \
+                   CompressedImage *padded_image);                                                                    \
+  virtual bool CompressAndPad(CompressedImage::Format format, uint32 height, uint32 width, uint32 padded_height,      \
+                              uint32 padded_width, uint32 padding_bytes_per_row, const uint8 *buffer,                 \
+                              CompressedImage *padded_image);                                                         \
+  virtual bool CreateSolidImage(CompressedImage::Format format, uint32 height, uint32 width, const uint8 *color,      \
+                                CompressedImage *image);                                                              \
+  virtual bool CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,       \
+                            uint32 width, CompressedImage *subimage)
+
 #endif  // IMAGE_COMPRESSION_PUBLIC_COMPRESSOR_H_
