@@ -11,6 +11,7 @@
 #ifndef ICAMD_PVRTC_BLOCK_H_
 #define ICAMD_PVRTC_BLOCK_H_
 
+#include "dxt_block.h"  // pk_lshr16
 #include "ic_device.h"
 #if defined(ICAMD_HOST_EMULATION)
 #include <string.h>
@@ -153,18 +154,6 @@ ICAMD_DEV uint32_t pvrtc_pixel_mod(uint32_t pixel, const PvrtcAB nb[3][3]) {
                          bilerp_pair(c00.b_rb, c01.b_rb, c10.b_rb, c11.b_rb, xw, yw),
                          bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw));
 }
-
-// v_pk_lshrrev_b16: logical shift right of both 16-bit lanes
-#if defined(ICAMD_HOST_EMULATION)
-ICAMD_DEV uint32_t pk_lshr16(uint32_t v, uint32_t sh) { return ((v & 0xffffu) >> sh) | ((v >> 16) >> sh) << 16; }
-#else
-typedef unsigned short icamd_pv_us2 __attribute__((ext_vector_type(2)));
-ICAMD_DEV uint32_t pk_lshr16(uint32_t v, uint32_t sh) {
-  const icamd_pv_us2 x = __builtin_bit_cast(icamd_pv_us2, v);
-  const icamd_pv_us2 s = { (unsigned short)sh, (unsigned short)sh };
-  return __builtin_bit_cast(uint32_t, x >> s);
-}
-#endif
 
 // Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
 #if defined(ICAMD_HOST_EMULATION)

@@ -35,6 +35,10 @@ def test_cxx_headers_compile_and_link_without_gpu():
 
 @pytest.mark.gpu
 def test_cxx_api_transcript_matches_reference():
+    if not os.path.exists(os.path.join(BUILD, "api_driver_amd")):
+        subprocess.check_call(["make", "-C", os.path.join(T.ROOT, "image-compression_amd")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(T.ROOT, "tests", "cxx"), os.path.join(BUILD, "api_driver_amd")],
+                              stdout=subprocess.DEVNULL)
     got = _run("api_driver_amd")
     want = open(GOLDEN).read()
     if got != want:
