@@ -104,7 +104,23 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
     T.oracle_encode(codec, sample, rows, size, comps, 0, strategy, threads=1)
     dt1 = time.perf_counter() - t1
     assert out is not None
+    ref_info = None
+    if T.have_ref():
+        # the compiled reference itself (oracle/_ref, built from /root/reference in the build container and shipped
+        # as a binary): single thread, its own entry point -- DXT1/ETC1 only exist for 3-byte pixels there
+        import numpy as np
+        compressor = {0: T.DXTC, 1: T.DXTC, 2: T.ETC, 3: T.PVRTC}[codec]
+        fmt = {0: T.RGB, 1: T.RGBA, 2: T.RGB, 3: T.RGBA}[codec]
+        rimg = sample if T.comps_of(fmt) == comps else np.ascontiguousarray(sample[..., :3])
+        t2 = time.perf_counter()
+        r = T.ref_compress(compressor, fmt, rimg.reshape(-1), rows, size, 0, strategy)
+        dt2 = time.perf_counter() - t2
+        if r is not None:
+            ref_info = {"value": rows * size / dt2 / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                        "entry_point": "%sCompressor::Compress(%s)" % ({T.DXTC: "Dxtc", T.ETC: "Etc", T.PVRTC: "Pvrtc"}[compressor],
+                                                                       {T.RGB: "kRGB", T.RGBA: "kRGBA"}[fmt])}
     return {
+        "reference_single_thread": ref_info,
         "value": rows * size / dt / 1e6, "unit": "Mpixels/s", "cores": threads if codec != 3 else 1, "kind": "port",
         "single_thread_value": rows * size / dt1 / 1e6,
         "sample": "oracle/ic_oracle.c (plain-C port of the reference, -O2), %dx%d px of one workload texture, "
