@@ -209,7 +209,7 @@ def main():
         "metric": "Mpixels/s encode (%s, %dx%d %s)" % (label, size, size, "RGBA8" if comps == 4 else "RGB888"),
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8 in / int32 arithmetic", "data": "synthetic (%s, seeded, generated on device)" % args.content,
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic (%s, seeded, generated on device)" % args.content,
         "config": {"workload": "%s encode of %d x %dx%d %s textures per GPU per step (one launch), device-resident"
                                % (label, batch, size, size, "RGBA8" if comps == 4 else "RGB888"),
                    "codec": args.workload, "textures_per_gpu_per_step": batch, "texture": [size, size],

@@ -1,0 +1,57 @@
+"""CPU tier: the C-ABI library builds, loads, exports every function include/ic_amd.h declares, answers the
+host-only queries like the reference, and -- without a GPU -- fails LOUDLY instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ic_testlib as T
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import ic_amd_loader
+    return ic_amd_loader.load_package()
+
+
+def declared_functions():
+    text = open(os.path.join(T.ROOT, "include", "ic_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(icamd_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(pkg.EXPORTS) == names  # the Python binding list is complete too
+
+
+def test_host_only_queries_match_the_oracle(pkg):
+    for compressor in (T.DXTC, T.ETC, T.PVRTC):
+        for fmt in (T.RGB, T.BGR, T.RGBA, T.BGRA):
+            for (h, w) in [(0, 5), (1, 1), (5, 5), (8, 8), (61, 59), (4096, 4096), (16, 32)]:
+                assert pkg.compute_compressed_data_size(compressor, fmt, h, w) == T.oracle_size(compressor, fmt, h, w)
+    lib = pkg.lib()
+    assert [lib.icamd_supports_format(T.ETC, f) for f in range(4)] == [1, 0, 0, 0]
+    assert [lib.icamd_supports_format(T.PVRTC, f) for f in range(4)] == [0, 0, 1, 0]
+    assert all(lib.icamd_supports_format(T.DXTC, f) for f in range(4))
+    assert pkg.kernel_name(T.DXT1, 4) == "icamd_dxt1_rgba8_kernel"
+
+
+def test_no_gpu_means_a_loud_error_not_a_cpu_result(pkg):
+    if pkg.lib().icamd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    img = T.s_noise(8, 8, 3)
+    with pytest.raises(pkg.BackendError):
+        pkg.compress_host(T.DXTC, T.RGB, img.reshape(-1), 8, 8)
+    out = np.zeros(32, np.uint8)
+    rc = pkg.lib().icamd_compress(T.DXTC, 2, T.RGB, 8, 8, 0, img.ctypes.data, out.ctypes.data, 32)
+    assert rc < 0 and not out.any()
+    assert b"no HIP device" in pkg.lib().icamd_last_error()
+    # argument errors are still reported the reference's way (false), before any device is needed
+    assert pkg.lib().icamd_compress(T.DXTC, 2, T.RGB, 0, 8, 0, img.ctypes.data, out.ctypes.data, 32) == 1
