@@ -29,12 +29,12 @@ __device__ __forceinline__ void dxt_encode_one(const GridParams &P, uint32_t k) 
     const bool one_pixel = (bcol * 4 >= P.width) && (brow * 4 >= P.height);
     const Out8 a = encode_dxt5_alpha_block(px, one_pixel);
     const Out8 c = encode_dxt_color_block(px, swap, true, stash);
-    uint4 o = make_uint4(a.lo, a.hi, c.lo, c.hi);  // alpha block then colour block, dxtc.cc:94-96
-    *reinterpret_cast<uint4 *>(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 16) = o;
+    // alpha block then colour block, dxtc.cc:94-96
+    store_stream16(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 16, a.lo, a.hi,
+                   c.lo, c.hi);
   } else {
     const Out8 c = encode_dxt_color_block(px, swap, false, stash);
-    uint2 o = make_uint2(c.lo, c.hi);
-    *reinterpret_cast<uint2 *>(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 8) = o;
+    store_stream8(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 8, c.lo, c.hi);
   }
 }
 

@@ -15,8 +15,7 @@ __device__ __forceinline__ void etc1_encode_one(const GridParams &P, uint32_t k)
   uint32_t px[16];
   load_block<COMPS>(src, P.height, P.width, P.row_stride, brow * 4, bcol * 4, px);
   const Out8 c = encode_etc1_block(px, P.etc_strategy);
-  *reinterpret_cast<uint2 *>(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 8) =
-      make_uint2(c.lo, c.hi);
+  store_stream8(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 8, c.lo, c.hi);
 }
 
 extern "C" {
