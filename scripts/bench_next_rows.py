@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Device-resident throughput of the SURVEY 8f "next" rows: block decoders, Downsample, Pad, DXT1->ETC1 transcode.
+Prints one line per kernel: Mpixels/s (source or result pixels, whichever is larger) and algorithmic GB/s."""
+import ctypes, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import ic_amd_loader
+pkg = ic_amd_loader.load_package()
+L = pkg.lib()
+dev = torch.device("cuda:0")
+n, batch = 4096, 16
+stream = torch.cuda.current_stream()
+sh = ctypes.c_void_p(stream.cuda_stream)
+
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps): fn()
+    e1.record(stream); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+g = torch.Generator(device=dev); g.manual_seed(1)
+for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2, 3, 8)]:
+    src = torch.randint(0, 256, (batch, n, n, comps if codec != 1 else 4), dtype=torch.uint8, device=dev, generator=g)
+    blocks = pkg.encode_device(codec, src, n, n, src.shape[-1], n_images=batch)
+    torch.cuda.synchronize()
+    del src
+    per_in = blocks.shape[1]
+    out_comps = 4 if codec == 1 else 3
+    out = torch.empty((batch, n * n * out_comps), dtype=torch.uint8, device=dev)
+    def dec():
+        rc = L.icamd_decode_device(codec, 0, n, n, 0, batch, per_in, out.shape[1], ctypes.c_void_p(blocks.data_ptr()),
+                                   ctypes.c_void_p(out.data_ptr()), sh)
+        assert rc == 0
+    t = timeit(dec)
+    px = batch * n * n
+    print("decode %-5s %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)" % (
+        name, px / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n))
+    # Downsample / Pad / transcode work on one image's grid per call: loop over the batch inside the timed region
+    compressor, fmt = (1, 0) if codec == 2 else (0, 0 if codec == 0 else 2)
+    dn = torch.empty((batch, per_in // 4), dtype=torch.uint8, device=dev)
+    def down():
+        for i in range(batch):
+            rc = L.icamd_downsample_device(compressor, 2, fmt, n, n, ctypes.c_void_p(blocks[i].data_ptr()),
+                                           ctypes.c_void_p(dn[i].data_ptr()), dn.shape[1], sh)
+            assert rc == 0
+    t = timeit(down, 5)
+    print("downsample %-5s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images)" % (
+        name, px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
+    if codec == 0:
+        work = blocks.clone()
+        def tr():
+            rc = L.icamd_transcode_dxt1_to_etc1_device(ctypes.c_void_p(work.data_ptr()), work.numel(), sh)
+            assert rc == 0
+        t = timeit(tr, 10)
+        print("transcode dxt1->etc1 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms)" % (px / t / 1e6, 2 * work.numel() / t / 1e9, t * 1e3))
+    del out, dn, blocks
+    torch.cuda.empty_cache()
