@@ -27,7 +27,7 @@ EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -77,6 +77,8 @@ def lib():
         L.icamd_transcode_dxt1_to_etc1.argtypes = [_vp, _sz]
         L.icamd_transcode_dxt1_to_etc1_device.restype = _ci
         L.icamd_transcode_dxt1_to_etc1_device.argtypes = [_vp, _sz, _vp]
+        L.icamd_compress_batch.restype = _ci
+        L.icamd_compress_batch.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp, _ci, _vp]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -222,3 +224,23 @@ def transcode_dxt1_to_etc1_host(blocks):
     b = np.frombuffer(blocks, np.uint8).copy()
     st = lib().icamd_transcode_dxt1_to_etc1(b.ctypes.data, b.size)
     return b.tobytes() if _check(st, "icamd_transcode_dxt1_to_etc1") else None
+
+
+def compress_batch_host(compressor, fmt, images, height, width, devices, *, padding_bytes_per_row=0,
+                        etc_strategy=ETC_SMALLER_ERROR):
+    """icamd_compress_batch: `images` = list of numpy uint8 arrays (host), `devices` = list of HIP ordinals.
+    Returns a list of bytes (None where the reference would return false)."""
+    import numpy as np
+    n = len(images)
+    size = compute_compressed_data_size(compressor, fmt, height, width)
+    srcs = [np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images]
+    outs = [np.zeros(max(size, 1), np.uint8) for _ in range(n)]
+    in_ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in srcs])
+    out_ptrs = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    devs = (ctypes.c_int * len(devices))(*devices)
+    statuses = (ctypes.c_int * n)()
+    st = lib().icamd_compress_batch(compressor, etc_strategy, fmt, height, width, padding_bytes_per_row, n, in_ptrs,
+                                    out_ptrs, size, devs, len(devices), statuses)
+    if st < 0:
+        _check(st, "icamd_compress_batch")
+    return [outs[i][:size].tobytes() if statuses[i] == OK else None for i in range(n)]

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "ic_launch.h"
 
@@ -464,6 +466,48 @@ int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes) {
   return staged_blockop(blocks, n_bytes, blocks, n_bytes - n_bytes % 8, true, [&](void *din, void *, hipStream_t s) {
     return icamd_transcode_dxt1_to_etc1_device(din, n_bytes, s);
   });
+}
+
+int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                         uint32_t padding_bytes_per_row, uint32_t n_images, const uint8_t *const *buffers,
+                         uint8_t *const *outs, size_t out_size, const int *devices, int n_devices, int *statuses) {
+  if (n_images == 0) return ICAMD_OK;
+  if (!buffers || !outs || !devices || n_devices <= 0) return fail(ICAMD_ERR_ARG, "icamd_compress_batch: null list");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  int visible = 0;
+  ICAMD_HIP(hipGetDeviceCount(&visible), "hipGetDeviceCount");
+  for (int d = 0; d < n_devices; ++d)
+    if (devices[d] < 0 || devices[d] >= visible) return fail(ICAMD_ERR_ARG, "icamd_compress_batch: bad device ordinal");
+  std::vector<int> local(n_images, ICAMD_OK);
+  std::vector<std::string> errors((size_t)n_devices);
+  std::vector<std::thread> workers;
+  workers.reserve((size_t)n_devices);
+  for (int d = 0; d < n_devices; ++d) {
+    workers.emplace_back([&, d]() {
+      // each worker owns its device context, stream and staging buffers (thread_local state of this library)
+      if (hipSetDevice(devices[d]) != hipSuccess) {
+        for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) local[i] = ICAMD_ERR_HIP;
+        errors[(size_t)d] = "hipSetDevice failed";
+        return;
+      }
+      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) {
+        local[i] = icamd_compress(compressor, etc_strategy, format, height, width, padding_bytes_per_row, buffers[i],
+                                  outs[i], out_size);
+        if (local[i] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
+      }
+    });
+  }
+  for (std::thread &t : workers) t.join();
+  int first = ICAMD_OK;
+  for (uint32_t i = 0; i < n_images; ++i) {
+    if (statuses) statuses[i] = local[i];
+    if (first == ICAMD_OK && local[i] != ICAMD_OK) first = local[i];
+  }
+  if (first < 0)
+    for (const std::string &e : errors)
+      if (!e.empty()) { g_last_error = e; break; }
+  return first;
 }
 
 #pragma GCC visibility pop

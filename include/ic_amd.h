@@ -147,6 +147,17 @@ int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t unco
 int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream);
 int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes);
 
+/* ---- multi-GPU from one process: a batch of independent images, host buffers ----
+ * Image i is compressed exactly like icamd_compress(compressor, ..., buffers[i], outs[i], out_size) on device
+ * devices[i % n_devices] (HIP device ordinals; a device may be listed more than once to get several in-flight
+ * streams on it).  One host worker thread per list entry drives its own stream and staging buffers, so copies and
+ * kernels of different devices overlap; images are independent, so there is no inter-device exchange and the
+ * results land directly in the caller's host buffers.  statuses[i] (optional) receives each image's status; the
+ * return value is ICAMD_OK if all are ICAMD_OK, otherwise the first non-OK status in image order. */
+int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
+                         uint32_t padding_bytes_per_row, uint32_t n_images, const uint8_t *const *buffers,
+                         uint8_t *const *outs, size_t out_size, const int *devices, int n_devices, int *statuses);
+
 /* ---- runtime ---- */
 int icamd_device_count(void);             /* HIP devices visible; 0 if none */
 const char *icamd_last_error(void);       /* thread-local message for the last negative status */

@@ -296,3 +296,19 @@ def test_blockops_match_oracle(pkg):
     assert pkg.transcode_dxt1_to_etc1_host(raw) == T.oracle_transcode(raw)
     enc = T.oracle_compress(T.DXTC, T.RGB, T.s_mixed(512, 512, 3, index=4), 512, 512)
     assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)
+
+
+def test_single_process_multi_device_batch(pkg):
+    # icamd_compress_batch: one worker thread, stream and staging set per device-list entry.  The GPU box has one
+    # GPU, so device 0 is listed several times, which exercises the same concurrency as several devices would.
+    n, h, w = 13, 96, 160
+    for compressor, fmt, codec in ((T.DXTC, T.RGB, T.DXT1), (T.DXTC, T.BGRA, T.DXT5), (T.ETC, T.RGB, T.ETC1)):
+        comps = T.comps_of(fmt)
+        imgs = [T.s_mixed(h, w, comps, index=i) for i in range(n)]
+        want = [T.oracle_compress(compressor, fmt, im, h, w) for im in imgs]
+        for devices in ([0], [0, 0, 0], [0] * 8):
+            assert pkg.compress_batch_host(compressor, fmt, imgs, h, w, devices) == want
+    imgs = [T.s_mixed(64, 64, 4, index=i) for i in range(6)]
+    assert pkg.compress_batch_host(T.PVRTC, T.RGBA, imgs, 64, 64, [0, 0, 0]) == \
+        [T.oracle_encode(T.PVRTC2, im, 64, 64, 4) for im in imgs]
+    assert pkg.compress_batch_host(T.ETC, T.RGBA, imgs, 64, 64, [0, 0]) == [None] * 6  # reference: false
