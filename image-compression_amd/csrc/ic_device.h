@@ -82,6 +82,11 @@ ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
 ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
 }
+ICAMD_DEV uint32_t avg_u8(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+  for (int i = 0; i < 4; ++i) r |= ((((a >> (8 * i)) & 0xff) + ((b >> (8 * i)) & 0xff)) >> 1) << (8 * i);
+  return r;
+}
 ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
   uint64_t v = ((uint64_t)hi << 32) | lo;
   uint32_t r = 0;
@@ -110,6 +115,8 @@ ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_
 ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
 // v_sad_u8: sum over the 4 bytes of |a.b - b.b|, plus c
 ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
+// v_lerp_u8 with a zero rounding operand: per byte (a + b) >> 1 -- four floor-averages in one instruction
+ICAMD_DEV uint32_t avg_u8(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }
 // v_alignbit_b32: low 32 bits of ({hi,lo} >> sh)
 ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 // v_perm_b32: byte i of the result = byte sel.b[i] of the 8-byte value {hi,lo}

@@ -165,28 +165,37 @@ ICAMD_DEV uint32_t opaque(uint32_t v) {
 }
 #endif
 
-// (4-yw)*top + yw*bot on a channel pair (both 16-bit lanes; <= 4*255 per lane).
+// 8 * ((4-yw)*top + yw*bot) on a channel pair (both 16-bit lanes; <= 8*4*255 per lane).
 ICAMD_DEV uint32_t vblend_pair(uint32_t yw, uint32_t top, uint32_t bot) {
-  if (yw == 0u) return top << 2;
-  if (yw == 2u) return (top + bot) << 1;
-  return yw == 1u ? 3u * top + bot : top + 3u * bot;
+  if (yw == 0u) return top << 5;
+  if (yw == 2u) return (top + bot) << 4;
+  return (yw == 1u ? 3u * top + bot : top + 3u * bot) << 3;
 }
 
-// Modulation value of one pixel from the horizontally accumulated sums P[] = 32 * (up-sampled A_rb, A_ga,
-// B_rb, B_ga); the value (0..3) is ADDED into `acc` at the byte whose unit is `unit` (1, 1<<8, ...).
-// Same decisions as best_modulation(), spelled with full-rate add/sub/and/shift-right wherever possible:
-//   5A+3B = 4(A+B) + (A-B), 3A+5B = 4(A+B) - (A-B)  (plain 32-bit arithmetic on the packed lanes is exact as
-//   long as every lane RESULT is in range, borrows between lanes cancel);
-//   "d1 < d0" is the sign of d1 - d0 smeared by an arithmetic shift.
+// floor((5a + 3b) / 8) per byte as three nested floor-averages: with m = (a+b)>>1,
+//   (b + m) >> 1 = floor((a + 3b) / 4)   and   (a + floor((a + 3b) / 4)) >> 1 = floor((5a + 3b) / 8)
+// (an integer can be moved inside a floor, and floor(floor(x/2)/2) = floor(x/4)); checked for all 65 536 pairs.
+constexpr bool blend53_is_nested_average() {
+  for (unsigned a = 0; a < 256; ++a)
+    for (unsigned b = 0; b < 256; ++b) {
+      const unsigned m = (a + b) >> 1;
+      if (((a + ((b + m) >> 1)) >> 1) != (5 * a + 3 * b) / 8) return false;
+    }
+  return true;
+}
+static_assert(blend53_is_nested_average(), "(5a+3b)/8 != avg(a, avg(b, avg(a,b)))");
+
+// Modulation value of one pixel from the horizontally accumulated sums P[] = 256 * (up-sampled A_rb, A_ga,
+// B_rb, B_ga) -- the reference's truncated 8-bit channels (pvrtc.cc:228-236, sum / 32) are therefore exactly the
+// HIGH BYTES of the four 16-bit lanes, and one v_perm_b32 per colour packs them as R,G,B,A.  The two intermediate
+// colours (5A+3B)/8 and (3A+5B)/8 (pvrtc.cc:111-135) are nested byte averages (v_lerp_u8, all four channels per
+// instruction), the four L1 distances are v_sad_u8.  The value (0..3) is ADDED into `acc` at the byte whose unit
+// is `unit` (1, 1<<8, ...).  Same decisions as best_modulation().
 ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t unit, uint32_t acc) {
-  const uint32_t kSel = 0x06020400u;  // bytes: lo.b0, hi.b0, lo.b2, hi.b2  = R, G, B, A
-  // per-lane shift (v_pk_lshrrev_b16): clean 8-bit values in both 16-bit lanes, no masking needed
-  const uint32_t a_rb = pk_lshr16(P[0], 5), a_ga = pk_lshr16(P[1], 5), b_rb = pk_lshr16(P[2], 5), b_ga = pk_lshr16(P[3], 5);
-  const uint32_t c0 = perm(a_ga, a_rb, kSel), c3 = perm(b_ga, b_rb, kSel);
-  const uint32_t s_rb = (a_rb + b_rb) << 2, d_rb = a_rb - b_rb;
-  const uint32_t s_ga = (a_ga + b_ga) << 2, d_ga = a_ga - b_ga;
-  const uint32_t c1 = perm((s_ga + d_ga) >> 3, (s_rb + d_rb) >> 3, kSel);
-  const uint32_t c2 = perm((s_ga - d_ga) >> 3, (s_rb - d_rb) >> 3, kSel);
+  const uint32_t kSel = 0x07030501u;  // bytes: lo.b1, hi.b1, lo.b3, hi.b3  = R, G, B, A
+  const uint32_t c0 = perm(P[1], P[0], kSel), c3 = perm(P[3], P[2], kSel);
+  const uint32_t m = avg_u8(c0, c3);
+  const uint32_t c1 = avg_u8(c0, avg_u8(c3, m)), c2 = avg_u8(c3, avg_u8(c0, m));
   const uint32_t d0 = sad_u8(pixel, c0, 0u), d1 = sad_u8(pixel, c1, 0u);
   const uint32_t d2 = sad_u8(pixel, c2, 0u), d3 = sad_u8(pixel, c3, 0u);
   const bool s1 = d1 < d0, s2 = s1 && d2 < d1, s3 = s2 && d3 < d2;  // stop at the first non-improving step
@@ -210,9 +219,10 @@ ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__popc(v); }
 // vertically once ((4-yw)*top + yw*bot), then walk each half row with P(xw+1) = P(xw) + (VR - VL):
 //   x_in 0..3: sources (left, centre), xw = 4..7, P(4) = 4 (VL + VR)
 //   x_in 4..7: sources (centre, right), xw = 0..3, P(0) = 8 VL
+// with everything pre-scaled by 8 (vblend_pair) so that P = 256 * colour: 16-bit lanes, max 65 280, no carries;
 //   pixel right of the row = x_in 0 of the next block: sources (centre, right), xw = 4
 // (a*c00 + b*c01 + c*c10 + d*c11 with a..d = (4-yw)(8-xw), (4-yw)xw, yw(8-xw), yw*xw is exactly
-//  (8-xw)*VL + xw*VR; the division by 32 happens once, in accumulate_mod.)
+//  (8-xw)*VL + xw*VR; the division by 32 is accumulate_mod's "take the high byte".)
 template <bool WITH_RIGHT>
 ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const PvrtcColors bot[3], const uint32_t *pixels,
                               uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
