@@ -32,26 +32,74 @@ ICAMD_DEV uint32_t pair_rb(uint32_t c) { return c & 0x00ff00ffu; }
 ICAMD_DEV uint32_t pair_ga(uint32_t c) { return (c >> 8) & 0x00ff00ffu; }
 ICAMD_DEV uint32_t unpair(uint32_t rb, uint32_t ga) { return rb | ga << 8; }
 
-// ApplyBitDepthReduction (pvrtc.cc:93-106) on one 8-bit channel.
-ICAMD_DEV uint32_t bit_depth_reduce(uint32_t v, uint32_t depth) {
+// ApplyBitDepthReduction (pvrtc.cc:93-106) on one 8-bit channel: keep the top `depth` bits, replicate them downwards.
+constexpr uint32_t bit_depth_reduce(uint32_t v, uint32_t depth) {
   const uint32_t e = v & (0xffu << (8 - depth)) & 0xffu;
-  uint32_t r = e | e >> depth;
-  if (depth <= 3) r |= e >> (2 * depth);
-  return r;
+  return e | e >> depth | (depth <= 3 ? e >> (2 * depth) : 0u);
 }
 
-// ApplyColorChannelReduction (pvrtc.cc:337-349).  Note the alpha 224..254 promotion: a translucent
-// colour whose alpha reduces to 255 keeps its 4/4/3(4)-bit RGB but is later stored as opaque.
-ICAMD_DEV uint32_t channel_reduce(uint32_t c, bool is_b) {
-  const uint32_t r = bfe(c, 0, 8), g = bfe(c, 8, 8), b = bfe(c, 16, 8), a = c >> 24;
-  const bool opaque = a == 255u;
-  const uint32_t r5 = bit_depth_reduce(r, 5), g5 = bit_depth_reduce(g, 5);
-  const uint32_t r4 = bit_depth_reduce(r, 4), g4 = bit_depth_reduce(g, 4);
-  const uint32_t bo = is_b ? bit_depth_reduce(b, 5) : bit_depth_reduce(b, 4);
-  const uint32_t bt = is_b ? bit_depth_reduce(b, 4) : bit_depth_reduce(b, 3);
-  const uint32_t a3 = bit_depth_reduce(a, 3);
-  return opaque ? (r5 | g5 << 8 | bo << 16 | 255u << 24) : (r4 | g4 << 8 | bt << 16 | a3 << 24);
+// ApplyColorChannelReduction (pvrtc.cc:337-349), channel by channel as the reference does it:
+//   colour A: opaque R5 G5 B4, translucent R4 G4 B3 A3;   colour B: opaque R5 G5 B5, translucent R4 G4 B4 A3.
+// Note the alpha 224..254 promotion: a translucent colour whose alpha reduces to 255 keeps its 4/4/3(4)-bit RGB
+// but is later stored as opaque (pvrtc_pack_colors tests the REDUCED alpha).
+constexpr uint32_t channel_reduce_by_channel(uint32_t c, bool is_b) {
+  const uint32_t r = c & 0xffu, g = (c >> 8) & 0xffu, b = (c >> 16) & 0xffu, a = c >> 24;
+  return a == 255u ? (bit_depth_reduce(r, 5) | bit_depth_reduce(g, 5) << 8 | bit_depth_reduce(b, is_b ? 5 : 4) << 16 | 255u << 24)
+                   : (bit_depth_reduce(r, 4) | bit_depth_reduce(g, 4) << 8 | bit_depth_reduce(b, is_b ? 4 : 3) << 16 |
+                      bit_depth_reduce(a, 3) << 24);
 }
+
+// The same on all four channels at once (SWAR on the RGBA dword): the shifted copies are masked so that nothing
+// crosses a byte boundary.  ~10 integer ops per colour instead of ~45.
+constexpr uint32_t channel_reduce(uint32_t c, bool is_b) {
+  uint32_t ro = 0, rt = 0;
+  if (is_b) {
+    const uint32_t eo = c & 0x00f8f8f8u;
+    ro = eo | ((eo >> 5) & 0x00070707u);
+    const uint32_t et = c & 0xe0f0f0f0u;
+    rt = et | ((et >> 4) & 0x000f0f0fu) | ((et >> 3) & 0x1c000000u) | ((et >> 6) & 0x03000000u);
+  } else {
+    const uint32_t eo = c & 0x00f0f8f8u;
+    ro = eo | ((eo >> 5) & 0x00000707u) | ((eo >> 4) & 0x000f0000u);
+    const uint32_t et = c & 0xe0e0f0f0u;
+    rt = et | ((et >> 4) & 0x00000f0fu) | ((et >> 3) & 0x1c1c0000u) | ((et >> 6) & 0x03030000u);
+  }
+  return (c >> 24) == 255u ? (ro | 0xff000000u) : rt;
+}
+// every value of every channel, next to all-zero and all-one neighbours, for both colours and both alpha classes
+constexpr bool channel_reduce_matches_reference() {
+  for (uint32_t v = 0; v < 256; ++v)
+    for (uint32_t sh = 0; sh < 32; sh += 8)
+      for (uint32_t bg = 0; bg < 2; ++bg)
+        for (uint32_t alpha_ff = 0; alpha_ff < 2; ++alpha_ff) {
+          uint32_t c = ((bg ? 0xffffffffu : 0u) & ~(0xffu << sh)) | v << sh;
+          if (alpha_ff) c |= 0xff000000u;
+          if (channel_reduce(c, false) != channel_reduce_by_channel(c, false)) return false;
+          if (channel_reduce(c, true) != channel_reduce_by_channel(c, true)) return false;
+        }
+  return true;
+}
+static_assert(channel_reduce_matches_reference(), "SWAR channel reduction differs from the per-channel form");
+
+// Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
+#else
+ICAMD_DEV uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+#endif
+
+// Scheduling fence: keeps hipcc from interleaving independent pixels / rows, which would multiply the live
+// registers (the encode kernel wants <= 64 VGPRs; thread-level parallelism covers the latency instead).
+#if defined(ICAMD_HOST_EMULATION)
+#define ICAMD_SCHED_FENCE() ((void)0)
+ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+#else
+#define ICAMD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__popc(v); }
+#endif
 
 // Per-lane 32-dword stash (same idea as BlockStash in dxt_block.h): pixel at a data-dependent index.
 #if defined(ICAMD_HOST_EMULATION)
@@ -62,9 +110,11 @@ struct Stash32 {
 };
 #else
 struct Stash32 {
-  uint32_t *base;       // &lds[0][thread][0]
-  uint32_t row_dwords;  // threads * 4
+  uint32_t *base;       // the lane's 4 dwords in plane 0
+  uint32_t row_dwords;  // distance between the 8 planes
+  bool filled = false;  // the kernel already placed the pixels (compile-time constant after inlining)
   __device__ __forceinline__ void put(const uint32_t px[32]) {
+    if (filled) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       *reinterpret_cast<uint4 *>(base + q * row_dwords) = make_uint4(px[4 * q], px[4 * q + 1], px[4 * q + 2], px[4 * q + 3]);
@@ -79,28 +129,35 @@ struct Stash32 {
 // Returns the two extreme colours, ordered so that colour A is not brighter than colour B.
 ICAMD_DEV void pvrtc_extremes(const uint32_t px[32], uint32_t image0, Stash32 &stash, uint32_t &col_a, uint32_t &col_b) {
   // keys: value*32 + p (min side) and value*32 + (31-p) (max side).  The max-side key is the min-side key
-  // plus (31 - 2p): one full-rate v_add_u32 instead of a second half-rate v_dot4.  Reductions in groups of
-  // two pixels so they become v_min3_u32 / v_max3_u32.
-  uint32_t kmin[5], kmax[5];
-  ICAMD_UNROLL
-  for (int i = 0; i < 5; ++i) { kmin[i] = 0xffffffffu; kmax[i] = 0u; }
+  // plus (31 - 2p): one full-rate add instead of recomputing it.  The lightness axis uses 32-bit keys; the R,B and
+  // G,A axes are packed two per dword (16-bit lanes, keys <= 255*32+31+31) and reduced with v_pk_min/max_u16.
+  uint32_t kmin_l = 0xffffffffu, kmax_l = 0u, kmin_rb = 0xffffffffu, kmax_rb = 0u, kmin_ga = 0xffffffffu, kmax_ga = 0u;
   ICAMD_UNROLL
   for (int p = 0; p < 32; p += 2) {
-    uint32_t lo[2][5];
+    uint32_t kl[2];
     ICAMD_UNROLL
     for (int q = 0; q < 2; ++q) {
-      const uint32_t c = px[p + q];
+      const uint32_t c = px[p + q], pp = (uint32_t)(p + q) * 0x00010001u, up = (uint32_t)(31 - 2 * (p + q)) * 0x00010001u;
       // lightness = (77r + 150g + 28b) / 256
-      lo[q][0] = ((udot4(c, 0x001c964du, 0u) >> 3) & ~31u) | (uint32_t)(p + q);
-      ICAMD_UNROLL
-      for (int ch = 0; ch < 4; ++ch) lo[q][ch + 1] = udot4(c, 32u << (8 * ch), (uint32_t)(p + q));
+      kl[q] = ((udot4(c, 0x001c964du, 0u) >> 3) & ~31u) | (uint32_t)(p + q);
+      const uint32_t k_rb = ((c << 5) & 0x1fe01fe0u) | pp, k_ga = ((c >> 3) & 0x1fe01fe0u) | pp;
+      kmin_rb = pk_min_u16(kmin_rb, k_rb);
+      kmin_ga = pk_min_u16(kmin_ga, k_ga);
+      kmax_rb = pk_max_u16(kmax_rb, k_rb + up);
+      kmax_ga = pk_max_u16(kmax_ga, k_ga + up);
     }
-    ICAMD_UNROLL
-    for (int i = 0; i < 5; ++i) {
-      kmin[i] = umin3(kmin[i], lo[0][i], lo[1][i]);
-      kmax[i] = umax3(kmax[i], lo[0][i] + (uint32_t)(31 - 2 * p), lo[1][i] + (uint32_t)(31 - 2 * (p + 1)));
+    kmin_l = umin3(kmin_l, kl[0], kl[1]);
+    kmax_l = umax3(kmax_l, kl[0] + (uint32_t)(31 - 2 * p), kl[1] + (uint32_t)(31 - 2 * (p + 1)));
+    if ((p & 6) == 6) {  // one pixel row at a time: stops the optimiser from regrouping the reductions by axis
+      kmin_l = opaque(kmin_l); kmax_l = opaque(kmax_l);  // (which keeps ~64 masked pixel values alive)
+      kmin_rb = opaque(kmin_rb); kmax_rb = opaque(kmax_rb);
+      kmin_ga = opaque(kmin_ga); kmax_ga = opaque(kmax_ga);
+      ICAMD_SCHED_FENCE();
     }
   }
+  // axis order of the reference: lightness, R, G, B, A (pvrtc.cc:259-266)
+  const uint32_t kmin[5] = { kmin_l, kmin_rb & 0xffffu, kmin_ga & 0xffffu, kmin_rb >> 16, kmin_ga >> 16 };
+  const uint32_t kmax[5] = { kmax_l, kmax_rb & 0xffffu, kmax_ga & 0xffffu, kmax_rb >> 16, kmax_ga >> 16 };
   stash.put(px);
   uint32_t best_diff = 0, best_lo = 0, best_hi = 0;
   ICAMD_UNROLL
@@ -155,16 +212,6 @@ ICAMD_DEV uint32_t pvrtc_pixel_mod(uint32_t pixel, const PvrtcAB nb[3][3]) {
                          bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw));
 }
 
-// Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
-#if defined(ICAMD_HOST_EMULATION)
-ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
-#else
-ICAMD_DEV uint32_t opaque(uint32_t v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-#endif
-
 // 8 * ((4-yw)*top + yw*bot) on a channel pair (both 16-bit lanes; <= 8*4*255 per lane).
 ICAMD_DEV uint32_t vblend_pair(uint32_t yw, uint32_t top, uint32_t bot) {
   if (yw == 0u) return top << 5;
@@ -202,16 +249,6 @@ ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t 
   return acc + ((uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3) * unit;
 }
 
-// Scheduling fence: keeps hipcc from interleaving independent pixels / rows, which would multiply the live
-// registers (the encode kernel wants <= 64 VGPRs; thread-level parallelism covers the latency instead).
-#if defined(ICAMD_HOST_EMULATION)
-#define ICAMD_SCHED_FENCE() ((void)0)
-ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
-#else
-#define ICAMD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-ICAMD_DEV uint32_t popcount_u32(uint32_t v) { return (uint32_t)__popc(v); }
-#endif
-
 // The 8 modulation values of one pixel row of a block (bytes of row[0..1], x order), and optionally the value of
 // the pixel just right of the row (first pixel of the right-hand block).  top[c] / bot[c], c = 0..2: reduced
 // colours of the block columns (left, centre, right) in the two block rows that bracket this pixel row;
@@ -231,7 +268,7 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const Pvrtc
   for (int c = 0; c < 3; ++c) {
     // opaque(): re-expand the colours for every pixel row instead of letting the compiler keep all 36
     // expanded pairs of the 3x3 neighbourhood alive across the whole block (4 full-rate ops per colour).
-    const uint32_t ta = opaque(top[c].a), tb = opaque(top[c].b), ba = opaque(bot[c].a), bb = opaque(bot[c].b);
+    const uint32_t ta = top[c].a, tb = top[c].b, ba = bot[c].a, bb = bot[c].b;
     V[c][0] = vblend_pair(yw, pair_rb(ta), pair_rb(ba));
     V[c][1] = vblend_pair(yw, pair_ga(ta), pair_ga(ba));
     V[c][2] = vblend_pair(yw, pair_rb(tb), pair_rb(bb));

@@ -18,8 +18,8 @@
 // through an LDS halo, two barriers) measured 1.0-1.25 ms per 16 x 4096^2 launch: with 50 KiB of LDS and a
 // fifth "ring" wave per workgroup it was latency/occupancy-bound (SQ_WAIT_ANY 50 %).  Recomputing 12 halo values
 // per lane (+37 % modulation work) removes every dependency between lanes.
-// Launch order is per image group (morph then encode) so the second read of the pixels hits the 256 MiB
-// Infinity Cache; toroidal wrap (pvrtc.cc:216-227,416-423) is applied to block / pixel coordinates.
+// Launch order is morph(all images of a group) then encode(same group), groups as large as the workspace allows
+// (see launch_pvrtc2); toroidal wrap (pvrtc.cc:216-227,416-423) is applied to block / pixel coordinates.
 #include "ic_launch.h"
 #include "ic_amd.h"
 #include "pvrtc_block.h"
@@ -167,10 +167,12 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   if (P.n_images == 0) return hipSuccess;
   const uint32_t bw = P.size / 8, bh = P.size / 4;
   const uint64_t bpi = (uint64_t)bw * bh;
-  // images per launch pair: keep the group's pixels (4 B/px) within ~half of the 256 MiB Infinity Cache so
-  // the encode kernel's re-read is served on-die; always at least one image
+  // Images per launch pair.  Both kernels are bound by instruction issue rather than HBM, so re-reading the pixels
+  // from HBM in the encode kernel costs nothing, while every launch boundary costs a drain/fill of ~4 waves per
+  // SIMD: measured 0.67 / 0.60 / 0.58 / 0.57 ms per 16 x 4096^2 for groups of 64 MiB / 128 MiB / 512 MiB / 1 GiB
+  // of pixels (r01).  So: as many images per launch as the 32-bit block index and a 256 MiB workspace allow.
   const uint64_t image_bytes = (uint64_t)P.size * P.size * 4u;
-  uint64_t group = image_bytes ? (128ull << 20) / image_bytes : 1;
+  uint64_t group = image_bytes ? (4096ull << 20) / image_bytes : 1;
   if (group < 1) group = 1;
   if (group > P.n_images) group = P.n_images;
   if (bpi * group >= (1ull << 31)) return hipErrorInvalidValue;
