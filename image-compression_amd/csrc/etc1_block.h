@@ -8,7 +8,7 @@
 // on the candidate, so we maximise E = 2 p.v - |v|^2 instead:
 //   * p.v is ONE v_dot4_u32_u8 on the packed pixel / candidate dwords (clamping is already baked
 //     into v, so this is exact for every base colour, unlike a Sum(d)-based shortcut);
-//   * key = 4*E + (3-k) folds the tie rule into a signed max (v_lshl_add_u32 + v_max3_i32);
+//   * key = 32*E + (3-k) folds the tie rule into a signed max (v_lshl_add_u32 + v_max3_i32); the key sum >> 5 is Sum(E);
 //   * the 2-bit winner is shifted into an index word with v_alignbit_b32;
 //   * the 32 candidates of a sub-block are built with packed saturating 16-bit adds
 //     (v_pk_add_u16 / v_pk_sub_u16 clamp on 0xRR00BB00) + one v_perm_b32 each;
@@ -82,7 +82,7 @@ constexpr int sub_pixel(int j) {
 }
 
 // The 4 candidate colours of one codeword (modifiers +a, +b, -a, -b; etc.cc:121-125 clamps each
-// channel to 0..255) as packed R,G,B,0 dwords, and the per-candidate constant (3-k) - 4|v|^2.
+// channel to 0..255) as packed R,G,B,0 dwords, and the per-candidate constant (3-k) - 32|v|^2.
 ICAMD_DEV void build_candidates(const EtcBase &base, uint32_t a, uint32_t b, uint32_t v[4], int32_t c[4]) {
   const uint32_t a2 = a * 0x01000100u, b2 = b * 0x01000100u;  // modifier in the high byte of both halves
   const uint32_t a1 = a << 8, b1 = b << 8;
@@ -93,12 +93,16 @@ ICAMD_DEV void build_candidates(const EtcBase &base, uint32_t a, uint32_t b, uin
   v[2] = perm(pk_subsat_u16(base.rb_hi, a2), pk_subsat_u16(base.g_hi, a1), sel);
   v[3] = perm(pk_subsat_u16(base.rb_hi, b2), pk_subsat_u16(base.g_hi, b1), sel);
   ICAMD_UNROLL
-  for (int k = 0; k < 4; ++k) c[k] = (3 - k) - 4 * (int32_t)udot4(v[k], v[k], 0u);
+  // opaque(): the constant must exist as one (negative) register so that every key is a single v_lshl_add_u32;
+  // left to itself the optimiser keeps +4|v|^2 for k = 3 and spends a shift and a subtract per pixel on it
+  for (int k = 0; k < 4; ++k) c[k] = (int32_t)opaque((uint32_t)((3 - k) - 32 * (int32_t)udot4(v[k], v[k], 0u)));
 }
 
 // ComputeCodewordError (etc.cc:350-385) for one codeword over the 8 pixels of a sub-block.
-// Returns 4 * Sum_p max_k E (the part of -error that depends on the codeword); *fields receives the
-// eight 2-bit values (3 - best_k) in bits 16..31, field j = pixel sub_pixel<FLIP,S>(j).
+// Per pixel and candidate the key is 32 E + (3 - k) with E = 2 p.v - |v|^2: the signed max picks the best E and, on
+// ties, the lowest k (etc.cc:366-379).  The eight tie-break fields add up to at most 24 < 32, so an arithmetic shift
+// of the key sum by 5 returns exactly Sum_p max_k E.  *fields receives the eight 2-bit values (3 - best_k) in bits
+// 16..31, field j = pixel sub_pixel<FLIP,S>(j).
 template <int FLIP, int S>
 ICAMD_DEV int32_t eval_codeword(const uint32_t px[16], const uint32_t v[4], const int32_t c[4], uint32_t *fields) {
   int32_t sum = 0;
@@ -106,23 +110,20 @@ ICAMD_DEV int32_t eval_codeword(const uint32_t px[16], const uint32_t v[4], cons
   ICAMD_UNROLL
   for (int j = 0; j < 8; ++j) {
     const uint32_t p = px[sub_pixel<FLIP, S>(j)];
-    const int32_t k0 = (int32_t)(udot4(p, v[0], 0u) << 3) + c[0];
-    const int32_t k1 = (int32_t)(udot4(p, v[1], 0u) << 3) + c[1];
-    const int32_t k2 = (int32_t)(udot4(p, v[2], 0u) << 3) + c[2];
-    const int32_t k3 = (int32_t)(udot4(p, v[3], 0u) << 3) + c[3];
-    const int32_t m = imax(imax3(k0, k1, k2), k3);  // 4E + (3-k): best E, ties -> lowest k
+    const int32_t k0 = (int32_t)(udot4(p, v[0], 0u) << 6) + c[0];
+    const int32_t k1 = (int32_t)(udot4(p, v[1], 0u) << 6) + c[1];
+    const int32_t k2 = (int32_t)(udot4(p, v[2], 0u) << 6) + c[2];
+    const int32_t k3 = (int32_t)(udot4(p, v[3], 0u) << 6) + c[3];
+    const int32_t m = imax(imax3(k0, k1, k2), k3);
     sum += m;
     acc = alignbit((uint32_t)m, acc, 2);
   }
   *fields = acc;
-  // remove the Sum(3-k) tie-break bits from the total: fields are pairs (lsb, msb) in bits 16..31
-  const uint32_t t = acc >> 16;
-  sum -= (int32_t)(popcount32(t & 0x5555u) + 2u * popcount32(t & 0xaaaau));
-  return sum;
+  return sum >> 5;
 }
 
 struct EtcSubResult {
-  int32_t score;    // 4 * Sum_p max_k E for the chosen codeword (larger = smaller error)
+  int32_t score;    // Sum_p max_k E for the chosen codeword (larger = smaller error)
   uint32_t cw;      // chosen codeword 0..7
   uint32_t fields;  // see eval_codeword
 };
@@ -134,21 +135,21 @@ struct EtcSubResult {
 //     f(+m) - f(-m) = 4 m s, and s = 0 ties go to the lower index, i.e. the positive side;
 //   * within the side, +/-a wins unless 2b|s| - 3b^2 > 2a|s| - 3a^2 (tie -> a, the lower index).
 // Per pixel and codeword that is 2 v_mad_i32_i24 + v_max_i32 instead of 4 dot4 + 4 shift-adds + 2 max.
-// abs_s[j] = |s| of pixel j of the sub-block.  Returns 4 * Sum_j max_m (2 m s - 3 m^2) (WITHOUT the E0 part);
+// abs_s[j] = |s| of pixel j of the sub-block.  Returns Sum_j max_m (2 m s - 3 m^2) (WITHOUT the E0 part);
 // *abits gets, in bits 24..31, bit j = 1 iff pixel j chose modifier magnitude a.
 ICAMD_DEV int32_t eval_codeword_unclamped(const uint32_t abs_s[8], int32_t a, int32_t b, uint32_t *abits) {
   int32_t sum = 0;
   uint32_t acc = 0;
   ICAMD_UNROLL
   for (int j = 0; j < 8; ++j) {
-    const int32_t ka = (int32_t)abs_s[j] * (8 * a) + (1 - 12 * a * a);  // 4 f(a) + 1: a wins ties
-    const int32_t kb = (int32_t)abs_s[j] * (8 * b) + (0 - 12 * b * b);  // 4 f(b)
+    const int32_t ka = imad24((int32_t)abs_s[j], 8 * a, 1 - 12 * a * a);  // 4 f(a) + 1: a wins ties
+    const int32_t kb = imad24((int32_t)abs_s[j], 8 * b, 0 - 12 * b * b);  // 4 f(b)
     const int32_t m = imax(ka, kb);
     sum += m;
     acc = alignbit((uint32_t)m, acc, 1);
   }
   *abits = acc;
-  return sum - (int32_t)popcount32(acc);
+  return (sum - (int32_t)popcount32(acc)) >> 2;  // keys are 4 f + tie bit: exact division
 }
 
 // 8 bits (bit j = pixel j) -> 16 bits (bit 2j)
@@ -168,17 +169,24 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
                                         const uint32_t bch[3], const uint32_t sub_sum[3]) {
   const uint32_t bsum = bch[0] + bch[1] + bch[2];
   const uint32_t bmin = umin3(bch[0], bch[1], bch[2]), bmax = umax3(bch[0], bch[1], bch[2]);
+  // The modifiers grow with the codeword, so once a codeword clamps somewhere in the wave every later one does too:
+  // `fast` is a wave-uniform flag that only ever goes from true to false, and when even codeword 0 clamps (bright /
+  // dark / saturated regions) none of the shortcut's per-pixel preparation is executed.
+  bool fast = wave_all(bmin >= (uint32_t)kEtcB[0] && bmax + (uint32_t)kEtcB[0] <= 255u);
   // per pixel |s| and the sign bits (bit 24+j = 1 iff s < 0), shared by all unclamped codewords
-  uint32_t abs_s[8], negbits = 0;
-  ICAMD_UNROLL
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t sp = psum[sub_pixel<FLIP, S>(j)];
-    abs_s[j] = sad_u32(sp, bsum, 0u);
-    negbits = alignbit((sp - bsum) >> 31, negbits, 1);
+  uint32_t abs_s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, negbits = 0;
+  int32_t e0_sum = 0;
+  if (fast) {
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t sp = psum[sub_pixel<FLIP, S>(j)];
+      abs_s[j] = sad_u32(sp, bsum, 0u);
+      negbits = alignbit((sp - bsum) >> 31, negbits, 1);
+    }
+    // Sum_j E0 = 2 * (base . sub_sum) - 8 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
+    e0_sum = 2 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
+           8 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
   }
-  // 4 * Sum_j E0 = 8 * (base . sub_sum) - 32 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
-  const int32_t e0x4 = 8 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
-                       32 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
   EtcSubResult r;
   r.score = 0; r.cw = 0; r.fields = 0;
   uint32_t fast_mask = 0;  // wave-uniform: bit cw set iff that codeword took the shortcut
@@ -186,8 +194,9 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   for (int cw = 0; cw < 8; ++cw) {
     int32_t s;
     uint32_t f;
-    if (wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u)) {
-      s = eval_codeword_unclamped(abs_s, kEtcA[cw], kEtcB[cw], &f) + e0x4;
+    if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
+    if (fast) {
+      s = eval_codeword_unclamped(abs_s, kEtcA[cw], kEtcB[cw], &f) + e0_sum;
       fast_mask |= 1u << cw;
     } else {
       uint32_t v[4];
@@ -234,7 +243,7 @@ ICAMD_DEV EtcSubResult heuristic_codeword(const uint32_t px[16], const EtcBase &
 }
 
 struct EtcFlipResult {
-  int32_t score;          // sum of both sub-block scores
+  int32_t score;          // sum of both sub-block scores (Sum over the 16 pixels of max_k E)
   uint32_t hi;            // high word (flip, diff, codewords, colours), etc.cc:43-61
   uint32_t f0, f1;        // index fields of sub-block 0 / 1
 };

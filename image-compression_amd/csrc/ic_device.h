@@ -98,6 +98,7 @@ ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
   return r;
 }
 ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
+ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
 ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
@@ -123,11 +124,24 @@ ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __bu
 // (selector 0..3 -> lo bytes, 4..7 -> hi bytes, 0x0c -> 0x00).
 ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+// v_mad_i32_i24: a * b + c.  PRECONDITION |a|, |b| < 2^23 (the compiler cannot prove it and would emit
+// v_mul_lo_u32 + v_add_u32 for the plain expression).
+ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
 ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return min(a, b); }
 ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return max(a, b); }
 ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return min(a, b); }
 ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return max(a, b); }
 
+#endif
+
+// Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
+#else
+ICAMD_DEV uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 #endif
 
 // The compiler folds these into v_min3/v_max3.

@@ -81,16 +81,6 @@ constexpr bool channel_reduce_matches_reference() {
 }
 static_assert(channel_reduce_matches_reference(), "SWAR channel reduction differs from the per-channel form");
 
-// Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
-#if defined(ICAMD_HOST_EMULATION)
-ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }
-#else
-ICAMD_DEV uint32_t opaque(uint32_t v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-#endif
-
 // Scheduling fence: keeps hipcc from interleaving independent pixels / rows, which would multiply the live
 // registers (the encode kernel wants <= 64 VGPRs; thread-level parallelism covers the latency instead).
 #if defined(ICAMD_HOST_EMULATION)
