@@ -72,6 +72,10 @@ ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {
   return c;
 }
 ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return (a > b ? a - b : b - a) + c; }
+ICAMD_DEV uint32_t sad_u16x2(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+  return (al > bl ? al - bl : bl - al) + (ah > bh ? ah - bh : bh - ah) + c;
+}
 ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
   for (int i = 0; i < 4; ++i) {
     int x = (a >> (8 * i)) & 0xff, y = (b >> (8 * i)) & 0xff;
@@ -114,6 +118,8 @@ ICAMD_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_
 // are both zero), which has a compiler builtin; v_sad_u32 only exists as inline asm, and every asm statement costs
 // hazard s_nops and blocks scheduling.
 ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
+// v_sad_u16 proper: |a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c
+ICAMD_DEV uint32_t sad_u16x2(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
 // v_sad_u8: sum over the 4 bytes of |a.b - b.b|, plus c
 ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
 // v_lerp_u8 with a zero rounding operand: per byte (a + b) >> 1 -- four floor-averages in one instruction

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: one clean (unprofiled) bench.py line per workload / content / ETC strategy -> gpurun_out/bench_all.jsonl
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/bench_all.jsonl; : > $O
+for wl in dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8; do
+  for c in noise smooth flat; do
+    python bench.py --steps 40 --warmup 5 --workload $wl --content $c --no-cpu-baseline 2>/dev/null | tail -1 >> $O
+  done
+done
+for s in 0 1 3; do python bench.py --steps 40 --warmup 5 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline 2>/dev/null | tail -1 >> $O; done
+python - <<'PY'
+import json
+for l in open("gpurun_out/bench_all.jsonl"):
+    d = json.loads(l)
+    print("%-12s %-6s strat=%s  %9.0f Mpix/s  %.4f ms/step  kernel %.4f ms  %7.1f GB/s  %s" % (
+        d["config"]["codec"], d["data"].split("(")[1].split(",")[0], d["config"].get("etc_strategy"), d["value"],
+        d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["achieved"], d["parity"][:9]))
+PY
