@@ -369,3 +369,46 @@ def ref_transcode(blocks, uh, uw):
     b = np.frombuffer(blocks, np.uint8).copy()
     _bind_ref_ops().ref_transcode_dxt1_to_etc1(uh, uw, _b4(uh), _b4(uw), _ptr(b), b.size)
     return b.tobytes()
+
+
+# ---- seeded random soak cases shared by the CPU tier (host-emulated kernel math) and the GPU tier
+
+SOAK_FORMATS = [(DXT1, 3, 0, 2), (DXT1, 3, 1, 2), (DXT1, 4, 0, 2), (DXT1, 4, 1, 2), (DXT5, 4, 0, 2), (DXT5, 4, 1, 2),
+                (ETC1, 3, 0, 0), (ETC1, 3, 0, 1), (ETC1, 3, 0, 2), (ETC1, 3, 0, 3), (ETC1, 4, 0, 2), (ETC1, 4, 0, 3)]
+
+
+def soak_image(rng, h, w, comps):
+    kind = int(rng.integers(0, 5))
+    if kind == 0:    # full-range noise
+        img = rng.integers(0, 256, (h, w, comps), dtype=np.uint8)
+    elif kind == 1:  # mid-tones only: every ETC1 codeword up to b = 80 stays unclamped (wave-uniform shortcut fires)
+        img = rng.integers(100, 156, (h, w, comps), dtype=np.uint8)
+    elif kind == 2:  # mid-tone left half, saturated right half: waves with and without clamping lanes
+        img = rng.integers(100, 156, (h, w, comps), dtype=np.uint8)
+        img[:, w // 2:] = rng.choice(np.array([0, 3, 252, 255], dtype=np.uint8), (h, w - w // 2, comps))
+    elif kind == 3:  # few distinct colours (constant-colour blocks, ties)
+        pal = rng.integers(0, 256, (3, comps), dtype=np.uint8)
+        img = pal[rng.integers(0, 3, (h // 4 + 1, w // 4 + 1))].repeat(4, axis=0).repeat(4, axis=1)[:h, :w]
+    else:            # gradients plus a little noise
+        y, x = np.mgrid[0:h, 0:w]
+        base = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) * 255 // max(h + w - 2, 1)),
+                         255 - (x * 255 // max(w - 1, 1))][:comps], axis=-1)
+        img = np.clip(base + rng.integers(-6, 7, base.shape), 0, 255).astype(np.uint8)
+    if comps == 4 and rng.integers(0, 2):  # alpha with exact 0 / 255 runs (DXT5 6-alpha mode, PVRTC opaque flags)
+        img = img.copy()
+        img[..., 3] = rng.choice(np.array([0, 255, 255, 255, 17, 128, 240], dtype=np.uint8), (h, w))
+    return np.ascontiguousarray(img)
+
+
+
+def soak_cases(seed, n_block_codecs, n_pvrtc, max_h=200, max_w=300, max_log2_pvrtc=5):
+    """Yields (codec, comps, swap, strategy, h, w, pad, img): random geometry, content and format."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for _ in range(n_block_codecs):
+        codec, comps, swap, strategy = SOAK_FORMATS[int(rng.integers(0, len(SOAK_FORMATS)))]
+        h, w, pad = int(rng.integers(1, max_h)), int(rng.integers(1, max_w)), int(rng.integers(0, 9))
+        yield codec, comps, swap, strategy, h, w, pad, soak_image(rng, h, w, comps)
+    for _ in range(n_pvrtc):  # PVRTC: square power-of-two RGBA images
+        size = 8 << int(rng.integers(0, max_log2_pvrtc + 1))
+        swap = int(rng.integers(0, 2))
+        yield PVRTC2, 4, swap, 0, size, size, 0, soak_image(rng, size, size, 4)

@@ -312,3 +312,18 @@ def test_single_process_multi_device_batch(pkg):
     assert pkg.compress_batch_host(T.PVRTC, T.RGBA, imgs, 64, 64, [0, 0, 0]) == \
         [T.oracle_encode(T.PVRTC2, im, 64, 64, 4) for im in imgs]
     assert pkg.compress_batch_host(T.ETC, T.RGBA, imgs, 64, 64, [0, 0]) == [None] * 6  # reference: false
+
+
+# ---- seeded random soak: many small images of random geometry / content / format against the oracle
+
+def test_random_soak_matches_oracle(pkg):
+    n = 0
+    for (codec, comps, swap, strategy, h, w, pad, img) in T.soak_cases(0x50AC, 260, 40):
+        src = T.with_row_padding(img, pad)
+        stride = w * comps + pad
+        want = T.oracle_encode(codec, src, h, w, comps, swap, strategy, stride=stride)
+        out = pkg.encode_device(codec, _dev(src), h, w, comps, swap_rb=bool(swap), etc_strategy=strategy,
+                                row_stride_bytes=stride)
+        assert _host(out) == want, (codec, comps, swap, strategy, h, w, pad)
+        n += 1
+    assert n == 300

@@ -151,3 +151,17 @@ def test_blockops_math_matches_oracle(emul):
     want = T.oracle_transcode(raw.tobytes())
     emul.emul_transcode(raw.ctypes.data, raw.size)
     assert raw.tobytes() == want
+
+
+def test_random_soak_host_emulation(emul):
+    """The GPU tier's soak (tests/test_gpu_parity.py) with the device math emulated on the host, smaller sizes."""
+    n = 0
+    for (codec, comps, swap, strategy, h, w, pad, img) in T.soak_cases(0x50AD, 120, 20, max_h=70, max_w=90,
+                                                                      max_log2_pvrtc=3):
+        src = T.with_row_padding(img, pad)
+        stride = w * comps + pad
+        want = T.oracle_encode(codec, src, h, w, comps, swap, strategy, stride=stride)
+        assert emul_encode(emul, codec, src, h, w, comps, swap, strategy, stride=stride) == want, \
+            (codec, comps, swap, strategy, h, w, pad)
+        n += 1
+    assert n == 140
