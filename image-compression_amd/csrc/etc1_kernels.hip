@@ -8,26 +8,25 @@
 namespace icamd {
 
 template <int COMPS>
-__device__ __forceinline__ void etc1_encode_one(const GridParams &P, uint32_t k) {
-  uint32_t img, brow, bcol;
-  locate_block(P, k, img, brow, bcol);
-  const uint8_t *src = P.src + (size_t)img * P.src_image_stride;
+__device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
+  const TileCoord t = locate_tile(P);
+  if (!t.valid) return;
+  const uint8_t *src = P.src + (size_t)t.img * P.src_image_stride;
   uint32_t px[16];
-  load_block<COMPS>(src, P.height, P.width, P.row_stride, brow * 4, bcol * 4, px);
+  if (t.brow * 4 + 4 <= P.height && t.bcol * 4 + 4 <= P.width) {
+    const TileSrc ts = tile_src<COMPS>(P, t);
+    load_block_interior<COMPS>(ts.base, ts.off, P.row_stride, px);
+  } else {
+    load_block<COMPS>(src, P.height, P.width, P.row_stride, t.brow * 4, t.bcol * 4, px);  // clamp-to-edge gather
+  }
   const Out8 c = encode_etc1_block(px, P.etc_strategy);
-  store_stream8(P.dst + (size_t)img * P.dst_image_stride + (size_t)(k - img * P.blocks_per_image) * 8, c.lo, c.hi);
+  store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
 }
 
 extern "C" {
 
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) {
-  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
-  if (k < P.total_blocks) etc1_encode_one<3>(P, k);
-}
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) {
-  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
-  if (k < P.total_blocks) etc1_encode_one<4>(P, k);
-}
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4>(P); }
 
 }  // extern "C"
 
@@ -35,12 +34,7 @@ const char *etc1_kernel_name(int comps) { return comps == 4 ? "icamd_etc1_rgba8_
 
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   if (P.total_blocks == 0) return hipSuccess;
-  const dim3 grid((P.total_blocks + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
-  if (comps == 4)
-    hipLaunchKernelGGL(icamd_etc1_rgba8_kernel, grid, block, 0, stream, P);
-  else
-    hipLaunchKernelGGL(icamd_etc1_rgb888_kernel, grid, block, 0, stream, P);
-  return hipGetLastError();
+  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, P, stream) : launch_tiled(icamd_etc1_rgb888_kernel, P, stream);
 }
 
 }  // namespace icamd

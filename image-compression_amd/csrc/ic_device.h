@@ -60,6 +60,7 @@ struct GridParams {
   uint32_t total_blocks;           // blocks_per_image * n_images
   uint32_t swap_rb;                // source is B,G,R(,A)
   uint32_t etc_strategy;
+  uint32_t log2_tile_cols;         // a workgroup covers 2^log2_tile_cols x (256 >> log2_tile_cols) blocks
   FastDiv div_bpi, div_cols;
 };
 
@@ -201,27 +202,82 @@ ICAMD_DEV void locate_block(const GridParams &P, uint32_t k, uint32_t &img, uint
   bcol = rem - brow * P.block_cols;
 }
 
+#if !defined(ICAMD_HOST_EMULATION)
+// Launch geometry of the encoders: grid = (column tiles, row tiles, images), one workgroup per tile of
+// 2^log2_tile_cols x (256 >> log2_tile_cols) blocks (256 x 1 for images at least 1024 pixels wide).  Image, tile row
+// and tile column are workgroup-uniform (blockIdx), so all 64-bit address arithmetic runs on the scalar unit and a
+// lane only adds a 32-bit offset (global_load ... v_off, s[base:base+1]); no division anywhere.  A wave still covers
+// 64 consecutive blocks of one block row (or whole rows of a narrower image).
+struct TileCoord {
+  uint32_t img, brow, bcol;  // this lane's block
+  uint32_t brow0, bcol0;     // first block of the workgroup's tile (uniform)
+  uint32_t ly, lx;           // the lane's position inside the tile
+  bool valid;
+};
+__device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
+  TileCoord t;
+  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
+  t.lx = threadIdx.x & (cols - 1u);
+  t.ly = threadIdx.x >> P.log2_tile_cols;
+  t.bcol0 = blockIdx.x * cols;
+  t.brow0 = blockIdx.y * rows;
+  t.bcol = t.bcol0 + t.lx;
+  t.brow = t.brow0 + t.ly;
+  t.img = blockIdx.z;
+  t.valid = t.bcol < P.block_cols && t.brow < P.block_rows;
+  return t;
+}
+// The block's first source byte = uniform 64-bit base + 32-bit lane offset (<= 4 * 256 rows of stride).
+struct TileSrc {
+  const uint8_t *base;  // workgroup-uniform
+  uint32_t off;         // per lane
+};
+template <int COMPS>
+__device__ __forceinline__ TileSrc tile_src(const GridParams &P, const TileCoord &t) {
+  TileSrc r;
+  r.base = P.src + (uint64_t)t.img * P.src_image_stride + (uint64_t)(t.brow0 * 4u) * P.row_stride +
+           (uint64_t)t.bcol0 * (4u * COMPS);
+  r.off = t.ly * 4u * P.row_stride + t.lx * (4u * COMPS);
+  return r;
+}
+// Address of the block's output bytes (BYTES per block, raster order inside the image).
+template <int BYTES>
+__device__ __forceinline__ uint8_t *tile_dst(const GridParams &P, const TileCoord &t) {
+  uint8_t *base = P.dst + (uint64_t)t.img * P.dst_image_stride +
+                  ((uint64_t)t.brow0 * P.block_cols + t.bcol0) * (uint64_t)BYTES;
+  return base + (uint32_t)((t.ly * P.block_cols + t.lx) * (uint32_t)BYTES);
+}
+#endif
+
 // Gather one 4x4 block (reference: internal/pixel4x4.h:44-67, pixel4x4.cc:23-59).
 // Interior blocks take 4 wide loads; edge blocks replicate the last row/column
 // (clamp-to-edge), byte by byte.
+// Interior block: four wide streaming loads.  `base` + `off` = address of the block's first pixel; the kernels pass
+// a workgroup-uniform base and a 32-bit lane offset so the loads use the scalar-base addressing mode.
+template <int COMPS>
+ICAMD_DEV void load_block_interior(const uint8_t *__restrict__ base, uint32_t off, uint32_t stride, uint32_t px[16]) {
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    // the row advance stays in the 32-bit lane offset (launch_tiled guarantees 1024 * stride < 2^32)
+    const uint8_t *row = base + (uint32_t)(off + (uint32_t)y * stride);
+    if (COMPS == 4) {
+      U4 v = load_stream(reinterpret_cast<const U4 *>(row));
+      px[4 * y + 0] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w;
+    } else {
+      U3 v = load_stream(reinterpret_cast<const U3 *>(row));
+      px[4 * y + 0] = v.x;
+      px[4 * y + 1] = alignbit(v.y, v.x, 24);
+      px[4 * y + 2] = alignbit(v.z, v.y, 16);
+      px[4 * y + 3] = v.z >> 8;
+    }
+  }
+}
+
 template <int COMPS>
 ICAMD_DEV void load_block(const uint8_t *__restrict__ img, uint32_t h, uint32_t w, uint32_t stride,
                           uint32_t row, uint32_t col, uint32_t px[16]) {
   if (row + 4 <= h && col + 4 <= w) {
-    const uint8_t *p = img + (size_t)row * stride + (size_t)col * COMPS;
-    ICAMD_UNROLL
-    for (int y = 0; y < 4; ++y) {
-      if (COMPS == 4) {
-        U4 v = load_stream(reinterpret_cast<const U4 *>(p + (size_t)y * stride));
-        px[4 * y + 0] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w;
-      } else {
-        U3 v = load_stream(reinterpret_cast<const U3 *>(p + (size_t)y * stride));
-        px[4 * y + 0] = v.x;
-        px[4 * y + 1] = alignbit(v.y, v.x, 24);
-        px[4 * y + 2] = alignbit(v.z, v.y, 16);
-        px[4 * y + 3] = v.z >> 8;
-      }
-    }
+    load_block_interior<COMPS>(img + (size_t)row * stride + (size_t)col * COMPS, 0u, stride, px);
   } else {
     ICAMD_UNROLL
     for (int y = 0; y < 4; ++y) {

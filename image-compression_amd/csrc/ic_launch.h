@@ -11,6 +11,34 @@ namespace icamd {
 
 constexpr int kThreadsPerWorkgroup = 256;  // 4 waves; one 4x4 block per lane
 
+// Tile shape for a block grid `block_cols` wide (GridParams::log2_tile_cols): the smallest power of two that covers
+// a block row, at most 256.
+inline uint32_t tile_log2_cols(uint32_t block_cols) {
+  uint32_t l = 0;
+  while (l < 8 && (1u << l) < block_cols) ++l;
+  return l;
+}
+// Launches `kernel` over every tile of every image; images go into grid.z in chunks of at most 65 535.
+template <typename Kernel>
+hipError_t launch_tiled(Kernel kernel, GridParams P, hipStream_t stream) {
+  const uint32_t n_images = P.blocks_per_image ? P.total_blocks / P.blocks_per_image : 0;
+  if (n_images == 0) return hipSuccess;
+  P.log2_tile_cols = tile_log2_cols(P.block_cols);
+  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
+  const uint32_t gx = (P.block_cols + cols - 1) / cols, gy = (P.block_rows + rows - 1) / rows;
+  if (gy > 65535u) return hipErrorInvalidValue;  // > 262 140 pixel rows
+  if ((uint64_t)P.row_stride * 1024u >= (1ull << 32) || (uint64_t)P.block_cols * 4096u >= (1ull << 32))
+    return hipErrorInvalidValue;                 // lane offsets inside a tile are 32-bit (rows of > 4 MiB)
+  for (uint32_t first = 0; first < n_images; first += 65535u) {
+    const uint32_t count = n_images - first < 65535u ? n_images - first : 65535u;
+    GridParams Q = P;
+    Q.src = P.src + (uint64_t)first * P.src_image_stride;
+    Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
+    hipLaunchKernelGGL(kernel, dim3(gx, gy, count), dim3(kThreadsPerWorkgroup), 0, stream, Q);
+  }
+  return hipGetLastError();
+}
+
 // codec: ICAMD_DXT1 / ICAMD_DXT5; comps: source bytes per pixel (3 or 4; DXT5 requires 4).
 hipError_t launch_dxt(int codec, int comps, const GridParams &P, hipStream_t stream);
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream);
