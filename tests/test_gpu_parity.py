@@ -120,6 +120,17 @@ def test_batch_launch_equals_per_image(pkg):
             assert out[i].cpu().numpy().tobytes() == T.oracle_encode(codec, imgs[i], h, w, comps)
 
 
+def test_batch_of_more_images_than_one_grid_dimension(pkg):
+    """70 000 images of 4x4 pixels in one call (grid.z holds 65 535): byte-identical to ONE 4 x 280 000 image."""
+    n = 70000
+    rng = np.random.Generator(np.random.PCG64(7))
+    for codec, comps in ((T.DXT1, 3), (T.ETC1, 3), (T.DXT5, 4)):
+        imgs = rng.integers(0, 256, (n, 4, 4, comps), dtype=np.uint8)
+        out = pkg.encode_device(codec, _dev(imgs), 4, 4, comps, n_images=n)
+        want = T.oracle_encode(codec, imgs.reshape(4 * n, 4, comps), 4 * n, 4, comps)
+        assert _host(out) == want, codec
+
+
 # ---- BASELINE.json full sizes
 
 def test_full_size_dxt1_4096_rgba8_and_rgb888(pkg):
