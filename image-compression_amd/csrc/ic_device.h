@@ -23,10 +23,12 @@
 #if defined(ICAMD_HOST_EMULATION)
 #define ICAMD_DEV static inline
 #define ICAMD_UNROLL
+#define ICAMD_NOUNROLL
 #else
 #include <hip/hip_runtime.h>
 #define ICAMD_DEV __device__ __forceinline__
 #define ICAMD_UNROLL _Pragma("unroll")
+#define ICAMD_NOUNROLL _Pragma("nounroll")
 #endif
 
 namespace icamd {

@@ -251,18 +251,15 @@ ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t 
 // (a*c00 + b*c01 + c*c10 + d*c11 with a..d = (4-yw)(8-xw), (4-yw)xw, yw(8-xw), yw*xw is exactly
 //  (8-xw)*VL + xw*VR; the division by 32 is accumulate_mod's "take the high byte".)
 template <bool WITH_RIGHT>
-ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const PvrtcColors bot[3], const uint32_t *pixels,
+ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB bot[3], const uint32_t *pixels,
                               uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
   uint32_t V[3][4];
   ICAMD_UNROLL
   for (int c = 0; c < 3; ++c) {
-    // opaque(): re-expand the colours for every pixel row instead of letting the compiler keep all 36
-    // expanded pairs of the 3x3 neighbourhood alive across the whole block (4 full-rate ops per colour).
-    const uint32_t ta = top[c].a, tb = top[c].b, ba = bot[c].a, bb = bot[c].b;
-    V[c][0] = vblend_pair(yw, pair_rb(ta), pair_rb(ba));
-    V[c][1] = vblend_pair(yw, pair_ga(ta), pair_ga(ba));
-    V[c][2] = vblend_pair(yw, pair_rb(tb), pair_rb(bb));
-    V[c][3] = vblend_pair(yw, pair_ga(tb), pair_ga(bb));
+    V[c][0] = vblend_pair(yw, top[c].a_rb, bot[c].a_rb);
+    V[c][1] = vblend_pair(yw, top[c].a_ga, bot[c].a_ga);
+    V[c][2] = vblend_pair(yw, top[c].b_rb, bot[c].b_rb);
+    V[c][3] = vblend_pair(yw, top[c].b_ga, bot[c].b_ga);
   }
   ICAMD_UNROLL
   for (int h = 0; h < 2; ++h) {
@@ -293,6 +290,23 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const Pvrtc
     for (int v = 0; v < 4; ++v) P[v] = (V[1][v] + V[2][v]) << 2;
     *right_mod = accumulate_mod(right_pixel, P, 1u, 0u);
   }
+}
+
+ICAMD_DEV PvrtcAB pvrtc_expand(const PvrtcColors &c) {
+  PvrtcAB e = { pair_rb(c.a), pair_ga(c.a), pair_rb(c.b), pair_ga(c.b) };
+  return e;
+}
+// the same from packed RGBA colours
+template <bool WITH_RIGHT>
+ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcColors top[3], const PvrtcColors bot[3], const uint32_t *pixels,
+                              uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
+  PvrtcAB t[3], b[3];
+  ICAMD_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    t[c] = pvrtc_expand(top[c]);
+    b[c] = pvrtc_expand(bot[c]);
+  }
+  pvrtc_row_mods<WITH_RIGHT>(yw, t, b, pixels, right_pixel, row, right_mod);
 }
 
 // All modulation values a block's encoding depends on, from its 3x3 block neighbourhood nb (toroidal wrap
@@ -435,6 +449,102 @@ ICAMD_DEV void pvrtc_encode_block_rows(RowLoader &load, const PvrtcColors nb[3][
   *data_out = mode == 0u ? d1 : d2;
 }
 
+// ---- strip form: one lane encodes K vertically adjacent blocks of one block column ---------------------------------
+// Walking down a column, the pixel row below a block IS row 0 of the next block, so the "below" halo row of
+// pvrtc_encode_block_rows (8 of its 12 redundant modulation values plus one row set-up) is computed once instead of
+// twice; only the last block of a strip still pays for it.  A block is finished (its mode decided, its words stored)
+// right after row 0 of the block under it.  44 -> 36 + 8/K modulation values per block.
+struct PvrtcBlockAcc {
+  uint32_t inter, hc, vc, d1, d2;
+};
+// one pixel row (y = 0..3, compile-time after unrolling) of a block: everything except the vertical differences
+ICAMD_DEV void pvrtc_acc_row(PvrtcBlockAcc &A, int y, const uint32_t row[2], uint32_t right_mod) {
+  A.vc = sad_u8(row[0], alignbit(row[1], row[0], 8), A.vc);   // "vertical_count" = sum |m - m(x+1, y)| (pvrtc.cc:426-429)
+  A.vc = sad_u8(row[1], alignbit(right_mod, row[1], 8), A.vc);
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t m = row[h];
+    A.inter += popcount_u32((m ^ (m >> 1)) & 0x01010101u);  // values 1 or 2: low bit xor high bit
+    const int pos = 8 * y + 4 * h;
+    A.d1 |= ((((m >> 1) & 0x01010101u) * 0x01020408u) >> 24) << pos;  // 1BPP: bit 8y+x = m >> 1
+    const uint32_t v = ((y & 1) ? m >> 8 : m) & 0x00030003u;           // 2BPP: checkerboard samples
+    A.d2 |= ((v | v >> 14) & 0xfu) << pos;
+  }
+}
+ICAMD_DEV uint32_t pvrtc_acc_finish(const PvrtcBlockAcc &A, bool *mode_1bpp) {
+  uint32_t mode = 1u;  // 0 = 1BPP, 1 = average-4, 2 = vertical, 3 = horizontal (pvrtc.cc:433-446)
+  if (A.inter <= 4u) mode = 0u;
+  else if (A.vc > 10u && A.vc > A.hc * 2u) mode = 2u;
+  else if (A.hc > 10u && A.hc > A.vc * 2u) mode = 3u;
+  uint32_t d2 = mode == 1u ? (A.d2 & ~1u) : (A.d2 | 1u);  // pvrtc.cc:474-487
+  d2 = mode == 2u ? (d2 | 1u << 20) : (d2 & ~(1u << 20));
+  *mode_1bpp = mode == 0u;
+  return mode == 0u ? A.d1 : d2;
+}
+
+// load_px(r, pixels[8], &right): pixel row r of the strip, r = 0 .. 4 K (row 4 K = first row of the block below the
+//                                strip), and the pixel right of it; toroidal wrap is the loader's business.
+// load_colours(j, c[3]):         reduced colours of block row j of the strip (j = -1 .. K), columns left/centre/right.
+// store(j, data, mode_1bpp, own): block j of the strip is finished; own = its reduced colours.
+template <typename PixelRowLoader, typename ColourRowLoader, typename BlockStore>
+ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, ColourRowLoader &load_colours,
+                                  BlockStore &store) {
+  PvrtcColors top[3], mid[3], bot[3];
+  load_colours(-1, top);
+  load_colours(0, mid);
+  load_colours(1, bot);
+  uint32_t cur[8], cur_right = 0, nxt[8], nxt_right = 0, prev[2] = { 0, 0 };
+  ICAMD_UNROLL
+  for (int i = 0; i < 8; ++i) nxt[i] = 0;
+  load_px(0u, cur, &cur_right);
+  PvrtcBlockAcc acc = { 0, 0, 0, 0, 0 };
+  PvrtcColors own = mid[1];
+  ICAMD_NOUNROLL
+  for (uint32_t j = 0;; ++j) {
+    // row 0 of block j -- for j == k_blocks the row below the strip, which only completes block K-1
+    if (j < k_blocks) load_px(4u * j + 1u, nxt, &nxt_right);
+    ICAMD_SCHED_FENCE();
+    uint32_t row[2], right_mod = 0;
+    pvrtc_row_mods<true>(2u, top, mid, cur, cur_right, row, &right_mod);
+    if (j > 0) {  // "horizontal_count" = sum |m - m(x, y+1)| across the block boundary, then block j-1 is complete
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      bool one_bpp;
+      const uint32_t data = pvrtc_acc_finish(acc, &one_bpp);
+      store(j - 1u, data, one_bpp, own);
+    }
+    if (j == k_blocks) break;
+    acc.inter = acc.hc = acc.vc = acc.d1 = acc.d2 = 0;
+    pvrtc_acc_row(acc, 0, row, right_mod);
+    prev[0] = row[0];
+    prev[1] = row[1];
+    ICAMD_UNROLL
+    for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    cur_right = nxt_right;
+    ICAMD_SCHED_FENCE();
+    ICAMD_UNROLL
+    for (int y = 1; y < 4; ++y) {
+      load_px(4u * j + (uint32_t)y + 1u, nxt, &nxt_right);
+      ICAMD_SCHED_FENCE();
+      if (y == 1) pvrtc_row_mods<true>(3u, top, mid, cur, cur_right, row, &right_mod);
+      else pvrtc_row_mods<true>((uint32_t)(y - 2), mid, bot, cur, cur_right, row, &right_mod);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row(acc, y, row, right_mod);
+      prev[0] = row[0];
+      prev[1] = row[1];
+      ICAMD_UNROLL
+      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+      cur_right = nxt_right;
+      ICAMD_SCHED_FENCE();
+    }
+    own = mid[1];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c) { top[c] = mid[c]; mid[c] = bot[c]; }
+    if (j + 1u < k_blocks) load_colours((int)j + 2, bot);
+  }
+}
+
 // FromZOrder inverse (pvrtc.cc:80-86): x occupies the odd bits, y the even bits of the block index.
 ICAMD_DEV uint32_t spread_bits16(uint32_t v) {
   v = (v | v << 8) & 0x00ff00ffu;
@@ -540,6 +650,31 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
       o[0] = data;
       o[1] = colors;
     }
+  // the strip encoder (what the kernel runs) must reproduce every block for several strip heights
+  for (uint32_t k_blocks = 1; k_blocks <= 8 && k_blocks <= bh; k_blocks *= 2)
+    for (uint32_t by0 = 0; by0 < bh; by0 += k_blocks)
+      for (uint32_t bx = 0; bx < bw; ++bx) {
+        auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
+          const uint32_t yy = (by0 * 4 + r) & (n - 1);
+          for (int x = 0; x < 8; ++x) pixels[x] = img[(size_t)yy * n + bx * 8 + x];
+          *right_px = img[(size_t)yy * n + ((bx * 8 + 8) & (n - 1))];
+        };
+        auto load_colours = [&](int j, PvrtcColors c[3]) {
+          const uint32_t yy = (by0 + bh + (uint32_t)j) % bh;
+          for (int dx = 0; dx < 3; ++dx) {
+            const size_t o2 = (size_t)yy * bw + (bx + bw + dx - 1) % bw;
+            c[dx].a = ca[o2];
+            c[dx].b = cb[o2];
+          }
+        };
+        int ok = 1;
+        auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
+          const uint32_t *o = reinterpret_cast<const uint32_t *>(out) + 2 * (size_t)pvrtc_z_index(bx, by0 + j);
+          if (o[0] != data || o[1] != pvrtc_pack_colors(own.a, own.b, one_bpp)) ok = 0;
+        };
+        pvrtc_encode_strip(k_blocks, load_px, load_colours, store);
+        if (!ok) return 0;
+      }
   delete[] ab; delete[] ca; delete[] cb; delete[] mods; delete[] self_right; delete[] self_below;
   return 1;
 }

@@ -6,13 +6,15 @@
 //   icamd_pvrtc2_morph_kernel   one 8x4 block per lane, raster order (a wave reads 64 x 32 B = 2 KiB contiguous
 //                               per pixel row): GetExtremesFast + ApplyColorChannelReduction -> the block's two
 //                               reduced colours, 8 B per block, into a workspace (0.25 B/px).           (Morph)
-//   icamd_pvrtc2_encode_kernel  one block per lane, lanes in Z-order (so a wave's 64 output blocks are 512
-//                               contiguous bytes, pvrtc.cc:551-580): re-reads its 32 pixels plus the pixel
-//                               column right of and the pixel row below the block (12 px), the 3x3 neighbourhood
-//                               of reduced colours, and computes ALL 44 modulation values its mode decision
-//                               depends on itself (pvrtc.cc:416-429 looks one pixel right / down), then the
-//                               modulation word and colour word.  No LDS, no barrier, no inter-lane exchange:
-//                               the reference's 1 B/px modulation image never exists.       (Modulate + Encode)
+//   icamd_pvrtc2_encode_kernel  one lane per vertical strip of 8 blocks of one block column; consecutive lanes =
+//                               consecutive columns (a wave reads 2 KiB contiguous per pixel row, its 8-byte block
+//                               stores land at the blocks' Z-order slots, pvrtc.cc:551-580).  The lane walks down
+//                               its 32 pixel rows plus the one below the strip, re-reading the pixels and the
+//                               pixel right of each row, keeps a rolling 3x3 neighbourhood of reduced colours,
+//                               and computes every modulation value its mode decisions depend on itself
+//                               (pvrtc.cc:416-429 looks one pixel right / down): 36 + 1 per block instead of the
+//                               32 a block owns.  No LDS, no barrier, no inter-lane exchange: the reference's
+//                               1 B/px modulation image never exists.                       (Modulate + Encode)
 //
 // A first fused version (one 320-lane workgroup per 16x16-block tile, A/B and modulation edges exchanged
 // through an LDS halo, two barriers) measured 1.0-1.25 ms per 16 x 4096^2 launch: with 50 KiB of LDS and a
@@ -30,16 +32,6 @@ namespace {
 
 constexpr int kMorphLanes = 256;
 constexpr int kEncodeLanes = 256;
-
-// compact the even bits of a 32-bit Z-order index (inverse of spread_bits16)
-__device__ __forceinline__ uint32_t compact_even_bits(uint32_t v) {
-  v &= 0x55555555u;
-  v = (v | v >> 1) & 0x33333333u;
-  v = (v | v >> 2) & 0x0f0f0f0fu;
-  v = (v | v >> 4) & 0x00ff00ffu;
-  v = (v | v >> 8) & 0x0000ffffu;
-  return v;
-}
 
 __device__ __forceinline__ void load_block32(const uint32_t *p, uint32_t n, uint32_t px[32]) {
 #pragma unroll
@@ -103,7 +95,9 @@ struct PvrtcLaunch {
   uint64_t src_image_stride, dst_image_stride;
   uint32_t size, log2_bw;   // width == height; log2(width / 8)
   uint32_t log2_bpi;        // log2(blocks per image)
+  uint32_t log2_strip;      // encode kernel: log2(blocks per lane), a vertical strip of one block column
   uint32_t total_blocks;    // blocks per image * images in this launch
+  uint32_t total_strips;    // total_blocks >> log2_strip
 };
 
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
@@ -126,39 +120,36 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_ker
 
 extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
   const uint32_t k = blockIdx.x * kEncodeLanes + threadIdx.x;
-  if (k >= L.total_blocks) return;
+  if (k >= L.total_strips) return;
   const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
-  const uint32_t image = k >> L.log2_bpi, z = k & ((1u << L.log2_bpi) - 1u);
-  const uint32_t bx = compact_even_bits(z >> 1), by = compact_even_bits(z);  // pvrtc.cc:80-86
+  const uint32_t log2_spi = L.log2_bpi - L.log2_strip;  // log2(strips per image)
+  // consecutive lanes = consecutive block columns of one strip row: a wave reads 2 KiB contiguous per pixel row
+  const uint32_t image = k >> log2_spi, s = k & ((1u << log2_spi) - 1u);
+  const uint32_t bx = s & bw_mask, by0 = (s >> L.log2_bw) << L.log2_strip;
   const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
   const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
+  uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
+  const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
 
-  PvrtcColors nb[3][3];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const uint32_t nx = (bx + dx - 1u) & bw_mask, ny = (by + dy - 1u) & bh_mask;
-      const uint2 c = ab[(ny << L.log2_bw) + nx];
-      nb[dy][dx].a = c.x;
-      nb[dy][dx].b = c.y;
-    }
-  const uint2 own = make_uint2(nb[1][1].a, nb[1][1].b);
-  // rows 0..3 of this block plus the first row of the block below (toroidal wrap), one row at a time
-  const uint32_t xr = ((bx + 1u) & bw_mask) * 8u;
-  const uint32_t row4 = ((by + 1u) & bh_mask) * 4u;
-  auto loader = [&](int r, uint32_t *pixels, uint32_t *right_px) {
-    const uint32_t *q = img + (size_t)(r < 4 ? by * 4u + (uint32_t)r : row4) * n;
+  auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
+    const uint32_t *q = img + (size_t)((by0 * 4u + r) & (n - 1u)) * n;
     const uint4 v0 = *reinterpret_cast<const uint4 *>(q + bx * 8u), v1 = *reinterpret_cast<const uint4 *>(q + bx * 8u + 4);
     pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
     pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
-    if (r < 4) *right_px = q[xr];
+    *right_px = q[xr * 8u];
   };
-  uint32_t data;
-  bool one_bpp;
-  pvrtc_encode_block_rows(loader, nb, &data, &one_bpp);
-  const uint32_t colors = pvrtc_pack_colors(own.x, own.y, one_bpp);
-  *reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride + (size_t)z * 8u) = make_uint2(data, colors);
+  auto load_colours = [&](int j, PvrtcColors c[3]) {
+    const uint2 *row = ab + (((by0 + (uint32_t)j) & bh_mask) << L.log2_bw);
+    const uint2 l = row[xl], m = row[bx], r = row[xr];
+    c[0].a = l.x; c[0].b = l.y;
+    c[1].a = m.x; c[1].b = m.y;
+    c[2].a = r.x; c[2].b = r.y;
+  };
+  const uint32_t zx = spread_bits16(bx) << 1;  // pvrtc.cc:80-86: x in the odd bits, y in the even bits
+  auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
+    dst[zx | spread_bits16(by0 + j)] = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
+  };
+  pvrtc_encode_strip(1u << L.log2_strip, load_px, load_colours, store);
 }
 
 const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_encode_kernel"; }
@@ -190,12 +181,16 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   L.size = P.size;
   L.log2_bw = P.log2_size - 3;
   L.log2_bpi = 2 * P.log2_size - 5;
+  // strip height: 8 blocks (32 pixel rows) amortise the one halo row per strip to 1/32 of the modulation work
+  // while a 4096^2 image still yields 1 024 waves; never more than the image's block rows (size / 4)
+  L.log2_strip = P.log2_size - 2 < 3 ? P.log2_size - 2 : 3;
   for (uint64_t first = 0; first < P.n_images; first += group) {
     const uint64_t count = (P.n_images - first < group) ? P.n_images - first : group;
     L.src = P.src + first * P.src_image_stride;
     L.dst = P.dst + first * P.dst_image_stride;
     L.total_blocks = (uint32_t)(bpi * count);
-    const dim3 gm((L.total_blocks + kMorphLanes - 1) / kMorphLanes), ge((L.total_blocks + kEncodeLanes - 1) / kEncodeLanes);
+    L.total_strips = L.total_blocks >> L.log2_strip;
+    const dim3 gm((L.total_blocks + kMorphLanes - 1) / kMorphLanes), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
     hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, L);
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
   }
