@@ -100,22 +100,40 @@ struct PvrtcLaunch {
   uint32_t total_strips;    // total_blocks >> log2_strip
 };
 
+// Morph: kMorphBlocksPerLane blocks per lane, software-pipelined with two pixel buffers -- the loads of the next
+// block are in flight while the current one is reduced, so a wave always has 8 KiB outstanding and the HBM stream
+// does not drain during its ~700-instruction compute phases (5 waves/SIMD: the 32 KiB stash caps the occupancy).
+constexpr int kMorphBlocksPerLane = 4;
+
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
   __shared__ uint32_t lds_stash[8][kMorphLanes][4];  // 32 KiB: per-lane pixel stash for index lookups
-  const uint32_t k = blockIdx.x * kMorphLanes + threadIdx.x;
-  if (k >= L.total_blocks) return;
-  const uint32_t n = L.size;
-  const uint32_t image = k >> L.log2_bpi, b = k & ((1u << L.log2_bpi) - 1u);
-  const uint32_t by = b >> L.log2_bw, bx = b & ((1u << L.log2_bw) - 1u);
-  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
-  uint32_t px[32];
-  load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+  const uint32_t k0 = blockIdx.x * (kMorphLanes * kMorphBlocksPerLane) + threadIdx.x;
+  const uint32_t n = L.size, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
   Stash32 stash;
   stash.base = &lds_stash[0][threadIdx.x][0];
   stash.row_dwords = kMorphLanes * 4;
-  uint32_t a, c;
-  pvrtc_extremes(px, img[0], stash, a, c);
-  L.ab[k] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+  auto fetch = [&](uint32_t k, uint32_t px[32]) {
+    const uint32_t image = k >> L.log2_bpi, b = k & bpi_mask;
+    const uint32_t by = b >> L.log2_bw, bx = b & bw_mask;
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+    load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+  };
+  auto reduce = [&](uint32_t k, const uint32_t px[32]) {
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)(k >> L.log2_bpi) * L.src_image_stride);
+    uint32_t a, c;
+    pvrtc_extremes(px, img[0], stash, a, c);
+    L.ab[k] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+  };
+  uint32_t buf_a[32], buf_b[32];
+  if (k0 < L.total_blocks) fetch(k0, buf_a);
+#pragma unroll
+  for (int i = 0; i < kMorphBlocksPerLane; i += 2) {
+    const uint32_t ka = k0 + (uint32_t)i * kMorphLanes, kb = ka + kMorphLanes, kc = kb + kMorphLanes;
+    if (kb < L.total_blocks) fetch(kb, buf_b);
+    if (ka < L.total_blocks) reduce(ka, buf_a);
+    if (i + 2 < kMorphBlocksPerLane && kc < L.total_blocks) fetch(kc, buf_a);
+    if (kb < L.total_blocks) reduce(kb, buf_b);
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
@@ -190,7 +208,8 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     L.dst = P.dst + first * P.dst_image_stride;
     L.total_blocks = (uint32_t)(bpi * count);
     L.total_strips = L.total_blocks >> L.log2_strip;
-    const dim3 gm((L.total_blocks + kMorphLanes - 1) / kMorphLanes), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
+    const uint32_t per_wg = kMorphLanes * kMorphBlocksPerLane;
+    const dim3 gm((L.total_blocks + per_wg - 1) / per_wg), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
     hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, L);
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
   }
