@@ -27,7 +27,7 @@ EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -79,6 +79,8 @@ def lib():
         L.icamd_transcode_dxt1_to_etc1_device.argtypes = [_vp, _sz, _vp]
         L.icamd_compress_batch.restype = _ci
         L.icamd_compress_batch.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp, _ci, _vp]
+        L.icamd_pvrtc2_encode_region_device.restype = _ci
+        L.icamd_pvrtc2_encode_region_device.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -224,6 +226,20 @@ def transcode_dxt1_to_etc1_host(blocks):
     b = np.frombuffer(blocks, np.uint8).copy()
     st = lib().icamd_transcode_dxt1_to_etc1(b.ctypes.data, b.size)
     return b.tobytes() if _check(st, "icamd_transcode_dxt1_to_etc1") else None
+
+
+def pvrtc_encode_region_device(src, size, first_block, n_blocks, *, out=None, stream=None):
+    """icamd_pvrtc2_encode_region_device: blocks [first_block, first_block + n_blocks) of the Z-order output of the
+    size x size RGBA8 image `src` (torch.uint8 CUDA tensor).  Returns the [8 * n_blocks] uint8 device tensor, or None
+    where the reference would refuse the size.  No synchronisation."""
+    assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+    if out is None:
+        out = torch.empty((8 * n_blocks,), dtype=torch.uint8, device=src.device)
+    st = lib().icamd_pvrtc2_encode_region_device(size, first_block, n_blocks, ctypes.c_void_p(src.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()), _stream_handle(stream))
+    if not _check(st, "icamd_pvrtc2_encode_region_device"):
+        return None
+    return out
 
 
 def compress_batch_host(compressor, fmt, images, height, width, devices, *, padding_bytes_per_row=0,

@@ -280,6 +280,28 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
   return ICAMD_OK;
 }
 
+int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint32_t n_blocks, const void *d_src,
+                                      void *d_dst_region, void *hip_stream) {
+  if (!d_src || !d_dst_region || n_blocks == 0) return ICAMD_FALSE;
+  if (!is_pow2(size) || size < 8) return ICAMD_FALSE;  // pvrtc.cc:640-646
+  const uint64_t blocks = (uint64_t)(size / 8) * (size / 4);
+  if (!is_pow2(n_blocks) || (first_block & (n_blocks - 1u)) != 0 || (uint64_t)first_block + n_blocks > blocks)
+    return fail(ICAMD_ERR_ARG, "PVRTC region must be a power-of-two, aligned range of the image's blocks");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  icamd::PvrtcParams P;
+  P.src = static_cast<const uint8_t *>(d_src);
+  P.dst = static_cast<uint8_t *>(d_dst_region);
+  P.src_image_stride = P.dst_image_stride = 0;
+  P.size = size;
+  P.log2_size = ilog2(size);
+  P.n_images = 1;
+  P.region_first = first_block;
+  P.region_blocks = n_blocks;
+  ICAMD_HIP(icamd::launch_pvrtc2(P, static_cast<hipStream_t>(hip_stream)), "launch pvrtc2 region");
+  return ICAMD_OK;
+}
+
 int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
                                   uint32_t height, uint32_t width,
                                   uint32_t padded_height, uint32_t padded_width,

@@ -51,6 +51,9 @@ struct PvrtcParams {
   uint32_t size;      // width == height
   uint32_t log2_size;
   uint32_t n_images;
+  // region_blocks != 0: encode only the blocks [region_first, region_first + region_blocks) of ONE image's Z-order
+  // output (a power-of-two, aligned range = a rectangle of blocks); dst receives just those 8 * region_blocks bytes
+  uint32_t region_first = 0, region_blocks = 0;
 };
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream);
 

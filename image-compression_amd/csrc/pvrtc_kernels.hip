@@ -97,7 +97,10 @@ struct PvrtcLaunch {
   uint32_t log2_bpi;        // log2(blocks per image)
   uint32_t log2_strip;      // encode kernel: log2(blocks per lane), a vertical strip of one block column
   uint32_t total_blocks;    // blocks per image * images in this launch
-  uint32_t total_strips;    // total_blocks >> log2_strip
+  uint32_t total_strips;    // encoded blocks of this launch >> log2_strip
+  // Encoded region of each image: the blocks whose Z-order index lies in [z_first, z_first + 2^log2_rblocks), a
+  // rectangle of 2^log2_rw x 2^(log2_rblocks - log2_rw) blocks at (rx0, ry0).  Whole image: 0, 0, log2_bw, log2_bpi, 0.
+  uint32_t rx0, ry0, log2_rw, log2_rblocks, z_first;
 };
 
 // Morph: kMorphBlocksPerLane blocks per lane, software-pipelined with two pixel buffers -- the loads of the next
@@ -136,14 +139,35 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_ker
   }
 }
 
+// Morph of a region plus its one-block ring (toroidal wrap), for encoding part of an image (one rank's share of a
+// PVRTC texture sharded by Z-order range): grid = (column chunks, rows) of the (rw + 2) x (rh + 2) rectangle.  Where
+// the ring wraps onto the region itself (a region as wide / tall as the image) a block is reduced twice to the same
+// value.  Single image only.
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rect_kernel(PvrtcLaunch L) {
+  __shared__ uint32_t lds_stash[8][kMorphLanes][4];
+  const uint32_t cx = blockIdx.x * kMorphLanes + threadIdx.x, rw = 1u << L.log2_rw;
+  if (cx >= rw + 2u) return;
+  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
+  const uint32_t bx = (L.rx0 + cx - 1u) & bw_mask, by = (L.ry0 + blockIdx.y - 1u) & bh_mask;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src);
+  uint32_t px[32];
+  load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+  Stash32 stash;
+  stash.base = &lds_stash[0][threadIdx.x][0];
+  stash.row_dwords = kMorphLanes * 4;
+  uint32_t a, c;
+  pvrtc_extremes(px, img[0], stash, a, c);
+  L.ab[(by << L.log2_bw) + bx] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+}
+
 extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
   const uint32_t k = blockIdx.x * kEncodeLanes + threadIdx.x;
   if (k >= L.total_strips) return;
   const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
-  const uint32_t log2_spi = L.log2_bpi - L.log2_strip;  // log2(strips per image)
+  const uint32_t log2_spi = L.log2_rblocks - L.log2_strip;  // log2(strips per image (region))
   // consecutive lanes = consecutive block columns of one strip row: a wave reads 2 KiB contiguous per pixel row
   const uint32_t image = k >> log2_spi, s = k & ((1u << log2_spi) - 1u);
-  const uint32_t bx = s & bw_mask, by0 = (s >> L.log2_bw) << L.log2_strip;
+  const uint32_t bx = L.rx0 + (s & ((1u << L.log2_rw) - 1u)), by0 = L.ry0 + ((s >> L.log2_rw) << L.log2_strip);
   const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
   const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
   uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
@@ -165,15 +189,66 @@ extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_k
   };
   const uint32_t zx = spread_bits16(bx) << 1;  // pvrtc.cc:80-86: x in the odd bits, y in the even bits
   auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
-    dst[zx | spread_bits16(by0 + j)] = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
+    dst[(zx | spread_bits16(by0 + j)) - L.z_first] = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
   };
   pvrtc_encode_strip(1u << L.log2_strip, load_px, load_colours, store);
 }
 
 const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_encode_kernel"; }
 
+namespace {
+// inverse of pvrtc_z_index on the host: x from the odd bits, y from the even bits
+uint32_t compact_even_bits_host(uint32_t v) {
+  v &= 0x55555555u;
+  v = (v | v >> 1) & 0x33333333u;
+  v = (v | v >> 2) & 0x0f0f0f0fu;
+  v = (v | v >> 4) & 0x00ff00ffu;
+  v = (v | v >> 8) & 0x0000ffffu;
+  return v;
+}
+}  // namespace
+
+// One image, blocks [z_first, z_first + n_blocks) of its Z-order output (n_blocks a power of two, z_first a multiple
+// of it: a rectangle of the block grid).  Reads the region's pixels and a one-block ring around it only.
+static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream) {
+  const uint32_t log2_bw = P.log2_size - 3, log2_bpi = 2 * P.log2_size - 5;
+  uint32_t m = 0;
+  while ((1u << m) < P.region_blocks) ++m;
+  if ((1u << m) != P.region_blocks || m > log2_bpi || (P.region_first & (P.region_blocks - 1u)) != 0 ||
+      (uint64_t)P.region_first + P.region_blocks > (1ull << log2_bpi))
+    return hipErrorInvalidValue;
+  uint2 *ab = nullptr;
+  hipError_t e = g_workspace.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
+  if (e != hipSuccess) return e;
+  PvrtcLaunch L;
+  L.src = P.src;
+  L.dst = P.dst;
+  L.ab = ab;
+  L.src_image_stride = L.dst_image_stride = 0;
+  L.size = P.size;
+  L.log2_bw = log2_bw;
+  L.log2_bpi = log2_bpi;
+  L.log2_rblocks = m;
+  L.log2_rw = m / 2;  // x owns the odd bits of the Z index: floor(m/2) of the low m bits
+  const uint32_t log2_rh = m - L.log2_rw;
+  L.rx0 = compact_even_bits_host(P.region_first >> 1);
+  L.ry0 = compact_even_bits_host(P.region_first);
+  L.z_first = P.region_first;
+  L.log2_strip = log2_rh < 3 ? log2_rh : 3;
+  L.total_blocks = 1u << log2_bpi;
+  L.total_strips = P.region_blocks >> L.log2_strip;
+  const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
+  const dim3 gm((rw + 2 + kMorphLanes - 1) / kMorphLanes, rh + 2), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
+  hipLaunchKernelGGL(icamd_pvrtc2_morph_rect_kernel, gm, dim3(kMorphLanes), 0, stream, L);
+  hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
+  e = hipGetLastError();
+  const hipError_t e2 = g_workspace.release(stream);
+  return e != hipSuccess ? e : e2;
+}
+
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   if (P.n_images == 0) return hipSuccess;
+  if (P.region_blocks != 0) return P.n_images == 1 ? launch_pvrtc2_region(P, stream) : hipErrorInvalidValue;
   const uint32_t bw = P.size / 8, bh = P.size / 4;
   const uint64_t bpi = (uint64_t)bw * bh;
   // Images per launch pair.  Both kernels are bound by instruction issue rather than HBM, so re-reading the pixels
@@ -202,6 +277,9 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   // strip height: 8 blocks (32 pixel rows) amortise the one halo row per strip to 1/32 of the modulation work
   // while a 4096^2 image still yields 1 024 waves; never more than the image's block rows (size / 4)
   L.log2_strip = P.log2_size - 2 < 3 ? P.log2_size - 2 : 3;
+  L.rx0 = L.ry0 = L.z_first = 0;
+  L.log2_rw = L.log2_bw;
+  L.log2_rblocks = L.log2_bpi;
   for (uint64_t first = 0; first < P.n_images; first += group) {
     const uint64_t count = (P.n_images - first < group) ? P.n_images - first : group;
     L.src = P.src + first * P.src_image_stride;

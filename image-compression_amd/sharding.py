@@ -2,6 +2,8 @@
 RCCL over xGMI on MI355X; "gloo" in the CPU test tier).
 
 Every 4x4 (DXT/ETC) block and every PVRTC texture is independent, so there is NO collective on the data path:
+  * one PVRTC texture can still be split by Z-order range (`pvrtc_region`): each rank recomputes the reduced colours
+    of a one-block ring around its rectangle instead of exchanging them;
   * a batch of textures is split into contiguous per-rank ranges (`texture_range`);
   * one large DXT/ETC image is split into contiguous slabs of block rows (`block_row_range`); blocks are stored
     row-major (reference compressor4x4_helper.h:202-214), so each slab's output is one contiguous byte range.
@@ -33,6 +35,32 @@ def slab_geometry(height, width, components, row_stride_bytes, block_bytes, worl
     return {"block_row0": b0, "block_rows": b1 - b0, "pixel_row0": y0, "pixel_rows": max(0, y1 - y0),
             "src_offset_bytes": y0 * row_stride_bytes, "dst_offset_bytes": b0 * cols * block_bytes,
             "dst_bytes": (b1 - b0) * cols * block_bytes}
+
+
+def pvrtc_region(size, world_size, rank):
+    """One PVRTC 2 bpp texture (size x size) sharded over `world_size` (a power of two) ranks by Z-order range: rank r
+    owns blocks [r * n, (r + 1) * n) of the output, n = blocks / world_size -- a rectangle of the block grid
+    (reference pvrtc_compressor.cc:80-86: x in the odd bits, y in the even bits of the block index) and one contiguous
+    byte range of the final buffer.  Returns dict(first_block, n_blocks, dst_offset_bytes, dst_bytes, block_x0,
+    block_y0, blocks_w, blocks_h): what to pass to icamd_pvrtc2_encode_region_device, where the bytes go, and which
+    blocks (plus a one-block toroidal ring, plus pixel (0, 0)) the rank has to hold."""
+    blocks = (size // 8) * (size // 4)
+    if world_size < 1 or world_size & (world_size - 1) or world_size > blocks:
+        raise ValueError("world_size must be a power of two not larger than the block count")
+    n = blocks // world_size
+    first = rank * n
+
+    def compact(v):  # every other bit of v, starting with bit 0
+        out, bit = 0, 0
+        while v:
+            out |= (v & 1) << bit
+            v >>= 2
+            bit += 1
+        return out
+    m = n.bit_length() - 1
+    return {"first_block": first, "n_blocks": n, "dst_offset_bytes": first * 8, "dst_bytes": n * 8,
+            "block_x0": compact(first >> 1), "block_y0": compact(first), "blocks_w": 1 << (m // 2),
+            "blocks_h": 1 << (m - m // 2)}
 
 
 def gather_output(local, world_size, dst=None, group=None):

@@ -76,6 +76,15 @@ int icamd_compress_and_pad(int compressor, int etc_strategy, int format,
                            uint32_t padding_bytes_per_row,
                            const uint8_t *buffer, uint8_t *out, size_t out_size);
 
+/* Multi-GPU sharding of ONE PVRTC texture: encodes only the blocks whose Z-order index
+ * (pvrtc_compressor.cc:80-86, :551-580) lies in [first_block, first_block + n_blocks) -- n_blocks a power of two,
+ * first_block a multiple of it, i.e. a rectangle of the block grid and ONE contiguous 8*n_blocks-byte range of the
+ * texture's output.  d_src is the whole size x size RGBA8 image (device); only the region's pixels and a one-block
+ * toroidal ring around it are read (the neighbours' colours are recomputed locally: no exchange between ranks).
+ * d_dst_region receives 8*n_blocks bytes.  ICAMD_FALSE where PvrtcCompressor::Compress would refuse the size. */
+int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint32_t n_blocks, const void *d_src,
+                                      void *d_dst_region, void *hip_stream);
+
 /* ---- the hot path, device-resident (the roofline entry points) ----
  * Same contracts, but `d_buffer` / `d_out` are device pointers on the current HIP
  * device and the work is enqueued on `hip_stream` (a hipStream_t, NULL = default

@@ -338,3 +338,39 @@ def test_random_soak_matches_oracle(pkg):
         assert _host(out) == want, (codec, comps, swap, strategy, h, w, pad)
         n += 1
     assert n == 300
+
+
+# ---- one PVRTC texture sharded by Z-order range: regions on one device == the whole image
+
+def test_pvrtc_region_sharding_of_one_image(pkg):
+    from image_compression_amd import sharding
+    rng = np.random.Generator(np.random.PCG64(0x9E))
+    for size, worlds in ((8, (1, 2)), (32, (2, 4, 8, 32)), (256, (2, 4, 8)), (1024, (8, 64))):
+        img = T.soak_image(rng, size, size, 4)
+        want = T.oracle_encode(T.PVRTC2, img, size, size, 4)
+        assert _host(pkg.encode_device(T.PVRTC2, _dev(img), size, size, 4)) == want
+        bw, bh = size // 8, size // 4
+        for world in worlds:
+            got = bytearray(len(want))
+            for rank in range(world):
+                g = sharding.pvrtc_region(size, world, rank)
+                # the rank's copy of the image: only its rectangle, a one-block ring (toroidal) and pixel (0, 0) are
+                # real; everything else is garbage and must not influence the result
+                keep = np.zeros((size, size), bool)
+                ys = [(g["block_y0"] - 1 + j) % bh for j in range(g["blocks_h"] + 2)]
+                xs = [(g["block_x0"] - 1 + i) % bw for i in range(g["blocks_w"] + 2)]
+                for by in ys:
+                    for bx in xs:
+                        keep[by * 4:by * 4 + 4, bx * 8:bx * 8 + 8] = True
+                keep[0, 0] = True
+                local = np.where(keep[..., None], img, rng.integers(0, 256, img.shape, dtype=np.uint8))
+                out = pkg.pvrtc_encode_region_device(_dev(local), size, g["first_block"], g["n_blocks"])
+                got[g["dst_offset_bytes"]:g["dst_offset_bytes"] + g["dst_bytes"]] = _host(out)
+            assert bytes(got) == want, (size, world)
+    # argument checks: misaligned / non power-of-two ranges are errors, bad sizes return false
+    src = _dev(np.zeros((32, 32, 4), np.uint8))
+    with pytest.raises(pkg.BackendError):
+        pkg.pvrtc_encode_region_device(src, 32, 3, 4)
+    with pytest.raises(pkg.BackendError):
+        pkg.pvrtc_encode_region_device(src, 32, 0, 6)
+    assert pkg.pvrtc_encode_region_device(src, 24, 0, 2) is None

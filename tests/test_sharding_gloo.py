@@ -90,3 +90,34 @@ def test_ranges_partition_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_pvrtc_regions_partition_the_block_grid():
+    """pvrtc_region: the ranks' Z-order ranges are disjoint rectangles that tile the block grid, and each rectangle's
+    blocks are exactly the blocks whose Z index (x in the odd bits, y in the even bits, pvrtc.cc:80-86) is in range."""
+    sh = _load_sharding()
+
+    def z_index(bx, by):
+        z = 0
+        for b in range(16):
+            z |= ((by >> b) & 1) << (2 * b) | ((bx >> b) & 1) << (2 * b + 1)
+        return z
+    for size in (8, 16, 64, 512):
+        bw, bh = size // 8, size // 4
+        for world in (1, 2, 4, 8, 16):
+            if world > bw * bh:
+                continue
+            owner = {}
+            for rank in range(world):
+                g = sh.pvrtc_region(size, world, rank)
+                assert g["n_blocks"] * world == bw * bh and g["blocks_w"] * g["blocks_h"] == g["n_blocks"]
+                assert g["dst_offset_bytes"] == 8 * g["first_block"] and g["dst_bytes"] == 8 * g["n_blocks"]
+                for by in range(g["block_y0"], g["block_y0"] + g["blocks_h"]):
+                    for bx in range(g["block_x0"], g["block_x0"] + g["blocks_w"]):
+                        assert (bx, by) not in owner and bx < bw and by < bh
+                        owner[(bx, by)] = rank
+                        assert g["first_block"] <= z_index(bx, by) < g["first_block"] + g["n_blocks"]
+            assert len(owner) == bw * bh
+    import pytest
+    with pytest.raises(ValueError):
+        sh.pvrtc_region(64, 3, 0)
