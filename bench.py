@@ -22,6 +22,7 @@ One JSON line is printed by rank 0.  Besides the driver contract it carries
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -246,6 +247,14 @@ def main():
             if got != want:
                 print(json.dumps(result))
                 sys.exit("parity check failed")
+            if codec != 3:
+                # informational: quality of the encoded texture 0, decoded again on the device
+                dec = pkg.decode_device(codec, out[0].contiguous(), size, size)
+                dcomps = 4 if codec == 1 else 3
+                a = dec.view(size, size, dcomps).to(torch.float64)
+                b = src[0][..., :dcomps].to(torch.float64)
+                mse = float(((a - b) ** 2).mean())
+                result["psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(T, codec, comps, size, args.etc_strategy, host0)
         print(json.dumps(result))
