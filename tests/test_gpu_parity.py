@@ -374,3 +374,34 @@ def test_pvrtc_region_sharding_of_one_image(pkg):
     with pytest.raises(pkg.BackendError):
         pkg.pvrtc_encode_region_device(src, 32, 0, 6)
     assert pkg.pvrtc_encode_region_device(src, 24, 0, 2) is None
+
+
+def test_concurrent_host_api_calls_from_several_threads(pkg):
+    """The reference has no mutable global state (threading): concurrent Compress calls must stay safe.
+    Four host threads hammer the host-buffer entry points (per-thread streams / staging / PVRTC workspace)."""
+    import threading
+    work = [(T.DXTC, T.RGB, 3, 2), (T.DXTC, T.RGBA, 4, 2), (T.ETC, T.RGB, 3, 2), (T.PVRTC, T.RGBA, 4, 2),
+            (T.ETC, T.RGB, 3, 3), (T.DXTC, T.BGR, 3, 2)]
+    cases = []
+    for i in range(24):
+        compressor, fmt, comps, strategy = work[i % len(work)]
+        n = 64 if compressor == T.PVRTC else 52 + 4 * (i % 5)
+        img = T.s_mixed(n, n, comps, index=100 + i)
+        cases.append((compressor, fmt, strategy, n, img, T.oracle_compress(compressor, fmt, img.reshape(-1), n, n,
+                                                                         strategy=strategy)))
+    failures = []
+
+    def run(tid):
+        for rep in range(3):
+            for j, (compressor, fmt, strategy, n, img, want) in enumerate(cases):
+                if (j + tid) % 4 and rep:  # different interleavings per thread
+                    continue
+                got = pkg.compress_host(compressor, fmt, img.reshape(-1), n, n, etc_strategy=strategy)
+                if got != want:
+                    failures.append((tid, j))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures[:5]
