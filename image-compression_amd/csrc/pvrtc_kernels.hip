@@ -32,6 +32,7 @@ namespace {
 
 constexpr int kMorphLanes = 256;
 constexpr int kEncodeLanes = 256;
+constexpr uint32_t kFullChipLanes = 256u * 4u * 64u * 2u;  // two waves on each of the 1 024 SIMDs
 
 __device__ __forceinline__ void load_block32(const uint32_t *p, uint32_t n, uint32_t px[32]) {
 #pragma unroll
@@ -108,9 +109,10 @@ struct PvrtcLaunch {
 // does not drain during its ~700-instruction compute phases (5 waves/SIMD: the 32 KiB stash caps the occupancy).
 constexpr int kMorphBlocksPerLane = 4;
 
-extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
+template <int kBlocksPerLane>
+__device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L) {
   __shared__ uint32_t lds_stash[8][kMorphLanes][4];  // 32 KiB: per-lane pixel stash for index lookups
-  const uint32_t k0 = blockIdx.x * (kMorphLanes * kMorphBlocksPerLane) + threadIdx.x;
+  const uint32_t k0 = blockIdx.x * (kMorphLanes * kBlocksPerLane) + threadIdx.x;
   const uint32_t n = L.size, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
   Stash32 stash;
   stash.base = &lds_stash[0][threadIdx.x][0];
@@ -129,14 +131,26 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_ker
   };
   uint32_t buf_a[32], buf_b[32];
   if (k0 < L.total_blocks) fetch(k0, buf_a);
+  if (kBlocksPerLane == 1) {
+    if (k0 < L.total_blocks) reduce(k0, buf_a);
+    return;
+  }
 #pragma unroll
-  for (int i = 0; i < kMorphBlocksPerLane; i += 2) {
+  for (int i = 0; i < kBlocksPerLane; i += 2) {
     const uint32_t ka = k0 + (uint32_t)i * kMorphLanes, kb = ka + kMorphLanes, kc = kb + kMorphLanes;
     if (kb < L.total_blocks) fetch(kb, buf_b);
     if (ka < L.total_blocks) reduce(ka, buf_a);
-    if (i + 2 < kMorphBlocksPerLane && kc < L.total_blocks) fetch(kc, buf_a);
+    if (i + 2 < kBlocksPerLane && kc < L.total_blocks) fetch(kc, buf_a);
     if (kb < L.total_blocks) reduce(kb, buf_b);
   }
+}
+
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
+  pvrtc2_morph<kMorphBlocksPerLane>(L);
+}
+// small launches (a few textures of <= 1024^2): one block per lane, four times as many workgroups
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_small_kernel(PvrtcLaunch L) {
+  pvrtc2_morph<1>(L);
 }
 
 // Morph of a region plus its one-block ring (toroidal wrap), for encoding part of an image (one rank's share of a
@@ -235,6 +249,7 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   L.ry0 = compact_even_bits_host(P.region_first);
   L.z_first = P.region_first;
   L.log2_strip = log2_rh < 3 ? log2_rh : 3;
+  while (L.log2_strip > 0 && (P.region_blocks >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
   L.total_blocks = 1u << log2_bpi;
   L.total_strips = P.region_blocks >> L.log2_strip;
   const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
@@ -277,6 +292,10 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   // strip height: 8 blocks (32 pixel rows) amortise the one halo row per strip to 1/32 of the modulation work
   // while a 4096^2 image still yields 1 024 waves; never more than the image's block rows (size / 4)
   L.log2_strip = P.log2_size - 2 < 3 ? P.log2_size - 2 : 3;
+  // ... and never so tall that a small launch leaves the chip empty: a strip is one long dependent instruction
+  // stream (~1 200 per block), so below ~2 waves per SIMD of strips, shorter strips finish sooner
+  // (one 1024^2 texture: 40 us with 8-block strips, a quarter of that with 1-block strips)
+  while (L.log2_strip > 0 && ((bpi * group) >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
   L.rx0 = L.ry0 = L.z_first = 0;
   L.log2_rw = L.log2_bw;
   L.log2_rblocks = L.log2_bpi;
@@ -286,9 +305,11 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     L.dst = P.dst + first * P.dst_image_stride;
     L.total_blocks = (uint32_t)(bpi * count);
     L.total_strips = L.total_blocks >> L.log2_strip;
-    const uint32_t per_wg = kMorphLanes * kMorphBlocksPerLane;
+    const bool small = L.total_blocks < (uint32_t)kMorphBlocksPerLane * kFullChipLanes;
+    const uint32_t per_wg = kMorphLanes * (small ? 1 : kMorphBlocksPerLane);
     const dim3 gm((L.total_blocks + per_wg - 1) / per_wg), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
-    hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, L);
+    if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, L);
+    else hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, L);
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
   }
   e = hipGetLastError();
