@@ -160,6 +160,27 @@ def test_full_size_dxt5_8192(pkg):
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
 
 
+def test_large_single_image_16384_dxt1(pkg):
+    """1 GiB source in one image (offsets beyond 2^30, 16 M blocks): hash against the oracle, which runs
+    slab-parallel on the host cores; plus a wide, short image whose block rows span many column tiles."""
+    import os
+    import torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    h = w = 16384
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    src = torch.randint(0, 256, (h, w, 4), dtype=torch.uint8, device="cuda", generator=g)
+    src[: h // 2, : w // 2] = 200  # constant-colour quadrant
+    out = pkg.encode_device(T.DXT1, src, h, w, 4)
+    got = _host(out)
+    want = T.oracle_encode(T.DXT1, src.cpu().numpy(), h, w, 4, threads=cores)
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    del src, out
+    h, w = 12, 70001  # ragged width, 17 501 block columns = 69 column tiles
+    img = T.s_mixed(h, w, 3, index=9)
+    assert _host(pkg.encode_device(T.ETC1, _dev(img), h, w, 3, etc_strategy=3)) == T.oracle_encode(T.ETC1, img, h, w, 3, 0, 3)
+
+
 def test_etc1_batch_1024(pkg):
     import torch
     # config 4 shape (1024x1024 textures, batch sharded over GPUs): a per-GPU sub-batch here, oracle on 2 of them
