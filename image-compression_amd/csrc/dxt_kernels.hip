@@ -12,18 +12,12 @@
 
 namespace icamd {
 
-template <int COMPS, bool DXT5>
+template <int COMPS, bool DXT5, bool WIDE>
 __device__ __forceinline__ void dxt_encode_one(const GridParams &P) {
-  const TileCoord t = locate_tile(P);
+  const TileCoord t = locate_tile<WIDE>(P);
   if (!t.valid) return;
-  const uint8_t *src = P.src + (size_t)t.img * P.src_image_stride;
   uint32_t px[16];
-  if (t.brow * 4 + 4 <= P.height && t.bcol * 4 + 4 <= P.width) {
-    const TileSrc ts = tile_src<COMPS>(P, t);
-    load_block_interior<COMPS>(ts.base, ts.off, P.row_stride, px);
-  } else {
-    load_block<COMPS>(src, P.height, P.width, P.row_stride, t.brow * 4, t.bcol * 4, px);  // clamp-to-edge gather
-  }
+  load_tile_block<COMPS>(P, t, px);
   const bool swap = P.swap_rb != 0;
   __shared__ uint32_t lds_px[4][kThreadsPerWorkgroup][4];
   BlockStash stash;
@@ -43,9 +37,13 @@ __device__ __forceinline__ void dxt_encode_one(const GridParams &P) {
 
 extern "C" {
 
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_kernel(GridParams P) { dxt_encode_one<4, false>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_kernel(GridParams P) { dxt_encode_one<3, false>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt5_rgba8_kernel(GridParams P) { dxt_encode_one<4, true>(P); }
+// *_kernel: 256 x 1-block tiles (block grids more than 128 columns wide); *_narrow_kernel: any tile shape
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_kernel(GridParams P) { dxt_encode_one<4, false, true>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_kernel(GridParams P) { dxt_encode_one<3, false, true>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt5_rgba8_kernel(GridParams P) { dxt_encode_one<4, true, true>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_narrow_kernel(GridParams P) { dxt_encode_one<4, false, false>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_narrow_kernel(GridParams P) { dxt_encode_one<3, false, false>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt5_rgba8_narrow_kernel(GridParams P) { dxt_encode_one<4, true, false>(P); }
 
 }  // extern "C"
 
@@ -58,9 +56,10 @@ hipError_t launch_dxt(int codec, int comps, const GridParams &P, hipStream_t str
   if (P.total_blocks == 0) return hipSuccess;
   if (codec == ICAMD_DXT5) {
     if (comps != 4) return hipErrorInvalidValue;
-    return launch_tiled(icamd_dxt5_rgba8_kernel, P, stream);
+    return launch_tiled(icamd_dxt5_rgba8_kernel, icamd_dxt5_rgba8_narrow_kernel, P, stream);
   }
-  return comps == 4 ? launch_tiled(icamd_dxt1_rgba8_kernel, P, stream) : launch_tiled(icamd_dxt1_rgb888_kernel, P, stream);
+  return comps == 4 ? launch_tiled(icamd_dxt1_rgba8_kernel, icamd_dxt1_rgba8_narrow_kernel, P, stream)
+                    : launch_tiled(icamd_dxt1_rgb888_kernel, icamd_dxt1_rgb888_narrow_kernel, P, stream);
 }
 
 }  // namespace icamd

@@ -7,26 +7,22 @@
 
 namespace icamd {
 
-template <int COMPS>
+template <int COMPS, bool WIDE>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = locate_tile(P);
+  const TileCoord t = locate_tile<WIDE>(P);
   if (!t.valid) return;
-  const uint8_t *src = P.src + (size_t)t.img * P.src_image_stride;
   uint32_t px[16];
-  if (t.brow * 4 + 4 <= P.height && t.bcol * 4 + 4 <= P.width) {
-    const TileSrc ts = tile_src<COMPS>(P, t);
-    load_block_interior<COMPS>(ts.base, ts.off, P.row_stride, px);
-  } else {
-    load_block<COMPS>(src, P.height, P.width, P.row_stride, t.brow * 4, t.bcol * 4, px);  // clamp-to-edge gather
-  }
+  load_tile_block<COMPS>(P, t, px);
   const Out8 c = encode_etc1_block(px, P.etc_strategy);
   store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
 }
 
 extern "C" {
 
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3, true>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4, true>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_narrow_kernel(GridParams P) { etc1_encode_one<3, false>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_narrow_kernel(GridParams P) { etc1_encode_one<4, false>(P); }
 
 }  // extern "C"
 
@@ -34,7 +30,8 @@ const char *etc1_kernel_name(int comps) { return comps == 4 ? "icamd_etc1_rgba8_
 
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   if (P.total_blocks == 0) return hipSuccess;
-  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, P, stream) : launch_tiled(icamd_etc1_rgb888_kernel, P, stream);
+  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_narrow_kernel, P, stream)
+                    : launch_tiled(icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_narrow_kernel, P, stream);
 }
 
 }  // namespace icamd

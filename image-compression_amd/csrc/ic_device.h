@@ -214,19 +214,26 @@ struct TileCoord {
   uint32_t img, brow, bcol;  // this lane's block
   uint32_t brow0, bcol0;     // first block of the workgroup's tile (uniform)
   uint32_t ly, lx;           // the lane's position inside the tile
-  bool valid;
+  bool full;                 // uniform: the whole tile lies inside the block grid
+  bool interior;             // uniform: every block of the tile lies inside the source image (4 wide loads each)
+  bool valid;                // this lane's block exists
 };
+// WIDE = the tile is 256 x 1 blocks (block grids more than 128 columns wide): the lane's row IS the tile's row, so every
+// row-dependent quantity is workgroup-uniform as well.
+template <bool WIDE>
 __device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
   TileCoord t;
-  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
-  t.lx = threadIdx.x & (cols - 1u);
-  t.ly = threadIdx.x >> P.log2_tile_cols;
+  const uint32_t cols = WIDE ? 256u : 1u << P.log2_tile_cols, rows = WIDE ? 1u : 256u >> P.log2_tile_cols;
+  t.lx = WIDE ? threadIdx.x : threadIdx.x & (cols - 1u);
+  t.ly = WIDE ? 0u : threadIdx.x >> P.log2_tile_cols;
   t.bcol0 = blockIdx.x * cols;
   t.brow0 = blockIdx.y * rows;
   t.bcol = t.bcol0 + t.lx;
   t.brow = t.brow0 + t.ly;
   t.img = blockIdx.z;
-  t.valid = t.bcol < P.block_cols && t.brow < P.block_rows;
+  t.full = t.bcol0 + cols <= P.block_cols && t.brow0 + rows <= P.block_rows;
+  t.interior = (t.bcol0 + cols) * 4u <= P.width && (t.brow0 + rows) * 4u <= P.height;
+  t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
   return t;
 }
 // The block's first source byte = uniform 64-bit base + 32-bit lane offset (<= 4 * 256 rows of stride).
@@ -242,6 +249,10 @@ __device__ __forceinline__ TileSrc tile_src(const GridParams &P, const TileCoord
   r.off = t.ly * 4u * P.row_stride + t.lx * (4u * COMPS);
   return r;
 }
+// Loads the lane's block: four wide loads when the block (for an interior tile: without looking) lies inside the
+// image, the clamp-to-edge gather otherwise.
+template <int COMPS>
+__device__ __forceinline__ void load_tile_block(const GridParams &P, const TileCoord &t, uint32_t px[16]);
 // Address of the block's output bytes (BYTES per block, raster order inside the image).
 template <int BYTES>
 __device__ __forceinline__ uint8_t *tile_dst(const GridParams &P, const TileCoord &t) {
@@ -295,6 +306,19 @@ ICAMD_DEV void load_block(const uint8_t *__restrict__ img, uint32_t h, uint32_t 
     }
   }
 }
+
+#if !defined(ICAMD_HOST_EMULATION)
+template <int COMPS>
+__device__ __forceinline__ void load_tile_block(const GridParams &P, const TileCoord &t, uint32_t px[16]) {
+  if (t.interior || (t.brow * 4u + 4u <= P.height && t.bcol * 4u + 4u <= P.width)) {
+    const TileSrc ts = tile_src<COMPS>(P, t);
+    load_block_interior<COMPS>(ts.base, ts.off, P.row_stride, px);
+  } else {
+    load_block<COMPS>(P.src + (size_t)t.img * P.src_image_stride, P.height, P.width, P.row_stride, t.brow * 4u,
+                      t.bcol * 4u, px);
+  }
+}
+#endif
 
 // Exact small-constant divisions on the operand ranges the encoders produce;
 // the ranges are checked exhaustively at compile time below.

@@ -20,7 +20,7 @@ inline uint32_t tile_log2_cols(uint32_t block_cols) {
 }
 // Launches `kernel` over every tile of every image; images go into grid.z in chunks of at most 65 535.
 template <typename Kernel>
-hipError_t launch_tiled(Kernel kernel, GridParams P, hipStream_t stream) {
+hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream) {
   const uint32_t n_images = P.blocks_per_image ? P.total_blocks / P.blocks_per_image : 0;
   if (n_images == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
@@ -34,7 +34,8 @@ hipError_t launch_tiled(Kernel kernel, GridParams P, hipStream_t stream) {
     GridParams Q = P;
     Q.src = P.src + (uint64_t)first * P.src_image_stride;
     Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
-    hipLaunchKernelGGL(kernel, dim3(gx, gy, count), dim3(kThreadsPerWorkgroup), 0, stream, Q);
+    hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(gx, gy, count),
+                       dim3(kThreadsPerWorkgroup), 0, stream, Q);
   }
   return hipGetLastError();
 }
