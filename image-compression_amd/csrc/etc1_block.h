@@ -14,7 +14,7 @@
 //     (v_pk_add_u16 / v_pk_sub_u16 clamp on 0xRR00BB00) + one v_perm_b32 each;
 //   * Sum|p|^2 over the 16 pixels is the same for both flips, so "error_lr <= error_tb"
 //     (etc.cc:583) is decided on Sum(E) alone.
-// ~3.8 k integer ops per block at kSmallerError: this codec is VALU-bound, not HBM-bound.
+// 3.5-4.3 k integer instructions per block at kSmallerError: this codec is VALU-bound, not HBM-bound.
 #ifndef ICAMD_ETC1_BLOCK_H_
 #define ICAMD_ETC1_BLOCK_H_
 

@@ -1,13 +1,16 @@
 // pvrtc_block.h -- PVRTC1 2bpp (8x4-pixel blocks) per-block and per-pixel math.
 //
 // Bit-exact with internal/pvrtc_compressor.cc (Morph :506-521, Modulate :527-540, Encode :551-580),
-// restructured so that one lane owns one 8x4 block with its 32 pixels in VGPRs:
+// restructured so that a lane owns whole 8x4 blocks with their pixels in VGPRs:
 //  * GetExtremesFast (:255-329): the 5 fitness axes' "first minimum / first maximum" become unsigned
-//    min / max reductions over keys value*32 + idx  /  value*32 + (31-idx); the R,G,B,A keys are one
-//    v_dot4_u32_u8 each (weight 32 on one byte, idx as accumulator);
+//    min / max reductions over keys value*32 + idx  /  value*32 + (31-idx): lightness is a v_dot4_u32_u8 with
+//    32-bit keys, the R,B and G,A channels are two 13-bit keys per dword reduced with v_pk_min/max_u16;
 //  * ColorDiff (:74-77), an L1 distance over 4 bytes, is one v_sad_u8;
-//  * the bilinear up-sampling (:173-237) works on 16-bit channel pairs 0x00RR00BB / 0x00GG00AA so
-//    two channels share each 24-bit multiply-add (max 32*255 = 8160 per lane: no carry between lanes).
+//  * ApplyColorChannelReduction (:337-349) is SWAR on the RGBA dword;
+//  * the bilinear up-sampling (:173-237) is separable and incremental on 16-bit channel pairs 0x00RR00BB /
+//    0x00GG00AA carried at scale 256 (max 65 280 per lane: no carry between lanes), so the truncated 8-bit
+//    channels are the lanes' high bytes; the 5:3 / 3:5 blends (:111-135) are nested v_lerp_u8 byte averages;
+//  * pvrtc_encode_strip: one lane walks a vertical strip of blocks, so the row below a block is computed once.
 #ifndef ICAMD_PVRTC_BLOCK_H_
 #define ICAMD_PVRTC_BLOCK_H_
 
