@@ -132,6 +132,10 @@ __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L) {
   uint32_t buf_a[32], buf_b[32];
   if (k0 < L.total_blocks) fetch(k0, buf_a);
   if (kBlocksPerLane == 1) {
+    // pin the eight loads together in front of the reduction (left alone, the optimiser sinks each row's loads
+    // down to its first use: four exposed memory round trips and 188 VGPRs)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) buf_a[i] = opaque(buf_a[i]);
     if (k0 < L.total_blocks) reduce(k0, buf_a);
     return;
   }
@@ -166,6 +170,8 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rec
   const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src);
   uint32_t px[32];
   load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) px[i] = opaque(px[i]);  // all eight loads in flight before the reduction starts
   Stash32 stash;
   stash.base = &lds_stash[0][threadIdx.x][0];
   stash.row_dwords = kMorphLanes * 4;
