@@ -21,5 +21,39 @@ for seed in range(n_seeds):
         if out.cpu().numpy().tobytes() != want:
             bad += 1
             print("MISMATCH", seed, codec, comps, swap, strategy, h, w, pad)
-print("parity soak: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
+print("encode soak: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
+
+# compressed-domain operations and decoders ("next" rows): random geometry, random content, all strategies
+rng = np.random.Generator(np.random.PCG64(0xB10C))
+ops = 0
+for it in range(60 * n_seeds):
+    compressor, fmt, strategy = [(T.DXTC, T.RGB, 2), (T.DXTC, T.BGR, 2), (T.DXTC, T.RGBA, 2), (T.DXTC, T.BGRA, 2),
+                                 (T.ETC, T.RGB, 0), (T.ETC, T.RGB, 1), (T.ETC, T.RGB, 2), (T.ETC, T.RGB, 3)][it % 8]
+    comps = T.comps_of(fmt)
+    h, w = int(rng.integers(1, 120)), int(rng.integers(1, 160))
+    img = T.soak_image(rng, h, w, comps)
+    blocks = T.oracle_compress(compressor, fmt, img.reshape(-1), h, w, 0, strategy)
+    ch, cw = 4 * ((h + 3) // 4), 4 * ((w + 3) // 4)
+    ph, pw = ch + 4 * int(rng.integers(0, 4)), cw + 4 * int(rng.integers(0, 4))
+    checks = [("downsample", pkg.downsample_host(compressor, fmt, blocks, h, w, strategy),
+               T.oracle_downsample(compressor, fmt, blocks, h, w, strategy))]
+    if (ph, pw) != (ch, cw):
+        checks.append(("pad", pkg.pad_host(compressor, fmt, blocks, ch, cw, ph, pw, strategy),
+                       T.oracle_pad(compressor, fmt, blocks, ch, cw, ph, pw, strategy)))
+    codec = T.ETC1 if compressor == T.ETC else (T.DXT1 if comps == 3 else T.DXT5)
+    swap = fmt in (T.BGR, T.BGRA)
+    pad = int(rng.integers(0, 6))
+    dec = pkg.decode_device(codec, torch.from_numpy(np.frombuffer(blocks, np.uint8).copy()).cuda(), h, w, swap_rb=swap,
+                            padding_bytes_per_row=pad)
+    torch.cuda.synchronize()
+    checks.append(("decode", dec.cpu().numpy().reshape(-1).tobytes(),
+                   np.asarray(T.oracle_decode(codec, blocks, h, w, swap=int(swap), pad=pad)).tobytes()))
+    if codec == T.DXT1:
+        checks.append(("transcode", pkg.transcode_dxt1_to_etc1_host(blocks), T.oracle_transcode(blocks)))
+    for name, got, want in checks:
+        ops += 1
+        if got != want:
+            bad += 1
+            print("MISMATCH", name, compressor, fmt, strategy, h, w, ph, pw, pad)
+print("block-op / decoder soak: %d checks, %d mismatches in total, %.1f s" % (ops, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
