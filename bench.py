@@ -249,12 +249,15 @@ def main():
                 sys.exit("parity check failed")
             if codec != 3:
                 # informational: quality of the encoded texture 0, decoded again on the device
-                dec = pkg.decode_device(codec, out[0].contiguous(), size, size)
-                dcomps = 4 if codec == 1 else 3
-                a = dec.view(size, size, dcomps).to(torch.float64)
-                b = src[0][..., :dcomps].to(torch.float64)
-                mse = float(((a - b) ** 2).mean())
-                result["psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
+                try:
+                    dec = pkg.decode_device(codec, out[0].contiguous(), size, size)
+                    dcomps = 4 if codec == 1 else 3
+                    a = dec.view(size, size, dcomps).to(torch.float64)
+                    b = src[0][..., :dcomps].to(torch.float64)
+                    mse = float(((a - b) ** 2).mean())
+                    result["psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
+                except Exception as e:  # never let the informational figure take the benchmark line down
+                    result["psnr_db"] = "unavailable: %s" % e
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(T, codec, comps, size, args.etc_strategy, host0)
         print(json.dumps(result))
