@@ -426,3 +426,28 @@ def test_concurrent_host_api_calls_from_several_threads(pkg):
     for t in threads:
         t.join()
     assert not failures, failures[:5]
+
+
+def test_device_entry_points_are_graph_capturable(pkg):
+    """The device entry points only enqueue kernels (and, for PVRTC, event records on a pre-grown workspace), so a
+    loop over many small textures can be captured once into a HIP graph and replayed (launch-bound regime)."""
+    import torch
+    n, size = 12, 64
+    imgs = np.stack([T.s_mixed(size, size, 4, index=300 + i) for i in range(n)])
+    src = _dev(imgs)
+    for codec in (T.DXT1, T.DXT5, T.ETC1, T.PVRTC2):
+        per = pkg.encoded_size(codec, size, size)
+        out = torch.zeros((n, per), dtype=torch.uint8, device="cuda")
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            pkg.encode_device(codec, src[0], size, size, 4, out=out[0:1], stream=s)  # warm-up (PVRTC workspace)
+            s.synchronize()
+            out.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for i in range(n):
+                    pkg.encode_device(codec, src[i], size, size, 4, out=out[i:i + 1], stream=s)
+            g.replay()
+            s.synchronize()
+        for i in range(n):
+            assert out[i].cpu().numpy().tobytes() == T.oracle_encode(codec, imgs[i], size, size, 4), (codec, i)
