@@ -75,9 +75,11 @@ struct EtcBase {
 // (etc.cc:131-137) so that the index field order equals the output bit order.
 //   FLIP=0 (left|right halves, etc.cc:466-467): x in {2S, 2S+1}, y = 0..3  -> bit 8S + j
 //   FLIP=1 (top|bottom halves, etc.cc:464-465): y in {2S, 2S+1}, x = 0..3 -> bit 4(j>>1) + 2S + (j&1)
+//   FLIP=2: the caller already gathered the 16 pixels in (sub-block, j) order for a per-lane flip
 template <int FLIP, int S>
 constexpr int sub_pixel(int j) {
-  return FLIP == 0 ? 4 * (j & 3) + (2 * S + (j >> 2))       // raster index 4y + x
+  return FLIP == 2 ? 8 * S + j
+       : FLIP == 0 ? 4 * (j & 3) + (2 * S + (j >> 2))       // raster index 4y + x
                    : 4 * (2 * S + (j & 1)) + (j >> 1);
 }
 
@@ -251,7 +253,7 @@ struct EtcFlipResult {
 // FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
 template <int FLIP>
 ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
-                                    const uint32_t s1[3], bool heuristic) {
+                                    const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
   uint32_t q5a[3], q5b[3];
   bool diff_mode = true;
@@ -262,7 +264,7 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
     const int32_t d = (int32_t)q5b[ch] - (int32_t)q5a[ch];
     diff_mode = diff_mode && d >= -4 && d <= 3;
   }
-  uint32_t hi = (uint32_t)FLIP;
+  uint32_t hi = flip_bit;
   uint32_t b0[3], b1[3];  // decoded base colours (what the decoder will reconstruct)
   if (diff_mode) {
     hi |= 2u;
@@ -360,7 +362,7 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   } else if (strategy == 1u) {  // kSplitVertically: left|right only
     res = encode_flip<0>(px, psum, left, right, false);
     flip = false;
-  } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574
+  } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574: one evaluation, partition chosen per lane
     // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
     uint32_t e_lr = 0, e_tb = 0;
     ICAMD_UNROLL
@@ -373,12 +375,24 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
       e_tb += dtb * dtb;
     }
     flip = !(e_lr > e_tb);
-    // both partitions are evaluated and the lane's choice selected, which keeps the wave convergent
-    const EtcFlipResult r0 = encode_flip<0>(px, psum, left, right, true);
-    const EtcFlipResult r1 = encode_flip<1>(px, psum, top, bottom, true);
-    res.hi = flip ? r1.hi : r0.hi;
-    res.f0 = flip ? r1.f0 : r0.f0;
-    res.f1 = flip ? r1.f1 : r0.f1;
+    // The partition differs per lane; instead of evaluating both (or diverging), every lane gathers its 16 pixels
+    // in the order of ITS partition -- (sub-block, j) as sub_pixel<flip> enumerates them -- with one v_cndmask per
+    // position that differs, and the single evaluation below runs on that list.
+    uint32_t pl[16];
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      pl[j] = sub_pixel<0, 0>(j) == sub_pixel<1, 0>(j) ? px[sub_pixel<0, 0>(j)]
+                                                       : (flip ? px[sub_pixel<1, 0>(j)] : px[sub_pixel<0, 0>(j)]);
+      pl[8 + j] = sub_pixel<0, 1>(j) == sub_pixel<1, 1>(j) ? px[sub_pixel<0, 1>(j)]
+                                                           : (flip ? px[sub_pixel<1, 1>(j)] : px[sub_pixel<0, 1>(j)]);
+    }
+    uint32_t sa[3], sb[3];
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      sa[ch] = flip ? top[ch] : left[ch];
+      sb[ch] = flip ? bottom[ch] : right[ch];
+    }
+    res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u);
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
     const EtcFlipResult r0 = encode_flip<0>(px, psum, left, right, false);
