@@ -236,6 +236,19 @@ def main():
             "algorithmic_bytes_per_pixel": bytes_per_px, "algorithmic_bytes_per_launch": int(algo_bytes),
             "read_roofline_frac": round((pixels_per_step_rank * comps / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS, 4),
         }
+        # Informational: how busy the integer VALU is.  Instructions per wave come from the committed PMC profile of
+        # this workload (SQ_INSTS_VALU / SQ_WAVES); a wave instruction occupies its SIMD for 4 clocks at the 16
+        # lanes/clk base rate, 1 024 SIMDs, 2.4 GHz.  Not a second roofline in the contract's sense.
+        spath = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload)
+        if os.path.exists(spath) and (size, batch) == (4096, 16):
+            with open(spath) as f:
+                kernels = json.load(f).get("kernels", {})
+            issue_s = 0.0
+            for kinfo in kernels.values():
+                if "valu_insts_per_wave" in kinfo and "SQ_WAVES" in kinfo:
+                    issue_s += kinfo["SQ_WAVES"] * kinfo["valu_insts_per_wave"] * 4.0 / (1024 * 2.4e9)
+            if issue_s > 0:
+                result["roofline"]["valu_issue_frac"] = round(issue_s / (kernel_ms * 1e-3), 3)
         import ic_testlib as T
         host0 = src[0].cpu().numpy()
         if not args.no_verify:
