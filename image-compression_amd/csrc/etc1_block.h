@@ -189,6 +189,41 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     e0_sum = 2 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
            8 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
   }
+  // Wave-uniform exact pruning of codewords that cannot win.  Every candidate of codeword cw differs from the base
+  // colour by at least min(a, room) in EVERY channel (room = distance of the base colour to the nearer clamp boundary,
+  // etc.cc:121-125), while every pixel of the sub-block is within `dev` of the base colour in every channel, so each
+  // pixel's error is at least 3 (min(a, room) - dev)^2 and the sub-block's at least 24 times that.  A codeword whose
+  // bound exceeds the error of the best one so far in every lane is skipped; the reference keeps the FIRST codeword
+  // with the strictly smallest error (etc.cc:401), so nothing it would pick is lost.  Two stages keep the cost off
+  // busy content: the L1 deviation (one v_sad_u8 per pixel) decides for the whole wave whether the per-channel
+  // maximum deviation is worth computing at all.
+  const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;
+  uint32_t d1 = 0;
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
+  const uint32_t room = umin(bmin, 255u - bmax);
+  // the per-channel deviation is at least a third of the L1 one: no codeword can be pruned unless 3 min(47, room) > d1
+  bool prunable = wave_all(d1 < 3u * umin((uint32_t)kEtcA[7], room));
+  uint32_t dev = 0;
+  int32_t sum_sq = 0;  // Sum_j |p_j|^2: error of a codeword = sum_sq - its score
+  if (prunable) {
+    uint32_t rb_max = 0, rb_min = 0xffffffffu, g_max = 0, g_min = 0xffu;
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t q = px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu;
+      sum_sq = (int32_t)udot4(q, q, (uint32_t)sum_sq);
+      const uint32_t rb = q & 0x00ff00ffu, g = q >> 8 & 0xffu;
+      rb_max = pk_max_u16(rb_max, rb);
+      rb_min = pk_min_u16(rb_min, rb);
+      g_max = umax(g_max, g);
+      g_min = umin(g_min, g);
+    }
+    const uint32_t base_rb = bch[0] | bch[2] << 16;
+    const uint32_t dev_rb = pk_max_u16(pk_subsat_u16(rb_max, base_rb), pk_subsat_u16(base_rb, rb_min));
+    const uint32_t dev_g = umax(g_max - umin(g_max, bch[1]), bch[1] - umin(bch[1], g_min));
+    dev = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
+    prunable = wave_all(dev < umin((uint32_t)kEtcA[7], room));
+  }
   EtcSubResult r;
   r.score = 0; r.cw = 0; r.fields = 0;
   uint32_t fast_mask = 0;  // wave-uniform: bit cw set iff that codeword took the shortcut
@@ -196,6 +231,10 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   for (int cw = 0; cw < 8; ++cw) {
     int32_t s;
     uint32_t f;
+    if (cw > 0 && prunable) {
+      const int32_t t = (int32_t)umin((uint32_t)kEtcA[cw], room) - (int32_t)dev;
+      if (wave_all(t > 0 && 24 * t * t > sum_sq - r.score)) continue;
+    }
     if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
     if (fast) {
       s = eval_codeword_unclamped(abs_s, kEtcA[cw], kEtcB[cw], &f) + e0_sum;

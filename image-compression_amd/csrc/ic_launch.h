@@ -19,11 +19,15 @@ inline uint32_t tile_log2_cols(uint32_t block_cols) {
   return l;
 }
 // Launches `kernel` over every tile of every image; images go into grid.z in chunks of at most 65 535.
+// max_log2_cols < 8 asks for squarer tiles (e.g. 4: 16 x 16 blocks, a wave = 16 x 4 blocks = 64 x 16 pixels):
+// worse coalescing, but the lanes of a wave see more homogeneous content, which is what wave-uniform shortcuts need.
 template <typename Kernel>
-hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream) {
+hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream,
+                        uint32_t max_log2_cols = 8) {
   const uint32_t n_images = P.blocks_per_image ? P.total_blocks / P.blocks_per_image : 0;
   if (n_images == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
+  if (P.log2_tile_cols > max_log2_cols) P.log2_tile_cols = max_log2_cols;
   const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
   const uint32_t gx = (P.block_cols + cols - 1) / cols, gy = (P.block_rows + rows - 1) / rows;
   if (gy > 65535u) return hipErrorInvalidValue;  // > 262 140 pixel rows
