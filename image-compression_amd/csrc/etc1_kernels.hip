@@ -19,10 +19,8 @@ __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
 
 extern "C" {
 
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3, true>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4, true>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_narrow_kernel(GridParams P) { etc1_encode_one<3, false>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_narrow_kernel(GridParams P) { etc1_encode_one<4, false>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3, false>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4, false>(P); }
 
 }  // extern "C"
 
@@ -34,8 +32,8 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   // decisions (unclamped shortcut, codeword pruning) fire far more often on compact waves, and at 7 % of the HBM
   // roofline the narrower loads cost nothing: noise 1.47 = 1.47 ms, smooth 1.85 -> 1.61 ms, flat 1.90 -> 1.72 ms (r01)
   const uint32_t cap = 4u;
-  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_narrow_kernel, P, stream, cap)
-                    : launch_tiled(icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_narrow_kernel, P, stream, cap);
+  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_kernel, P, stream, cap)
+                    : launch_tiled(icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_kernel, P, stream, cap);
 }
 
 }  // namespace icamd
