@@ -35,6 +35,9 @@ ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
   return (ah > bh ? ah - bh : 0u) << 16 | (al > bl ? al - bl : 0u);
 }
 ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+ICAMD_DEV uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+  return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c;
+}
 #else
 typedef unsigned short icamd_us2 __attribute__((ext_vector_type(2)));
 // v_pk_add_u16 ... clamp / v_pk_sub_u16 ... clamp
@@ -47,6 +50,10 @@ ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
                                                                      __builtin_bit_cast(icamd_us2, b)));
 }
 ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__popc(v); }
+// v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi + c
+ICAMD_DEV uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(icamd_us2, a), __builtin_bit_cast(icamd_us2, b), c, false);
+}
 #endif
 
 // True iff the predicate holds in every active lane of the wave (the emulation has one "lane").
@@ -189,23 +196,24 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     e0_sum = 2 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
            8 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
   }
-  // Wave-uniform exact pruning of codewords that cannot win.  Every candidate of codeword cw differs from the base
-  // colour by at least min(a, room) in EVERY channel (room = distance of the base colour to the nearer clamp boundary,
-  // etc.cc:121-125), while every pixel of the sub-block is within `dev` of the base colour in every channel, so each
-  // pixel's error is at least 3 (min(a, room) - dev)^2 and the sub-block's at least 24 times that.  A codeword whose
-  // bound exceeds the error of the best one so far in every lane is skipped; the reference keeps the FIRST codeword
-  // with the strictly smallest error (etc.cc:401), so nothing it would pick is lost.  Two stages keep the cost off
-  // busy content: the L1 deviation (one v_sad_u8 per pixel) decides for the whole wave whether the per-channel
-  // maximum deviation is worth computing at all.
+  // Wave-uniform exact pruning of codewords that cannot win.  In channel c every candidate on the positive side of
+  // codeword cw (+a, +b) differs from the base colour by at least min(a_cw, 255 - base_c), every one on the negative
+  // side by at least min(a_cw, base_c) (clamping, etc.cc:121-125, can only shorten a step down to the distance to the
+  // boundary), while every pixel of the sub-block lies within dev_c of the base colour.  A pixel's error under cw is
+  // therefore at least min over the two sides of Sum_c (step_c - dev_c)^2 (terms clipped at 0), the sub-block's 8 times
+  // that.  A codeword whose bound exceeds the error of the best one so far in every lane is skipped; the reference
+  // keeps the FIRST codeword with the strictly smallest error (etc.cc:401), so nothing it would pick is lost.  Two
+  // stages keep the cost off busy content: the L1 deviation (one v_sad_u8 per pixel) decides for the whole wave
+  // whether the per-channel deviations are worth computing at all.
   const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;
   uint32_t d1 = 0;
   ICAMD_UNROLL
   for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
-  const uint32_t room = umin(bmin, 255u - bmax);
-  // the per-channel deviation is at least a third of the L1 one: no codeword can be pruned unless 3 min(47, room) > d1
-  bool prunable = wave_all(d1 < 3u * umin((uint32_t)kEtcA[7], room));
-  uint32_t dev = 0;
-  int32_t sum_sq = 0;  // Sum_j |p_j|^2: error of a codeword = sum_sq - its score
+  // a per-channel deviation is at least a third of the L1 one, and no step exceeds a_7 = 47
+  bool prunable = wave_all(d1 < 3u * (uint32_t)kEtcA[7]);
+  uint32_t dev_rb = 0, dev_g = 0;      // per-channel maximum deviation: R | B << 16, G
+  uint32_t room_rb_up = 0, room_rb_dn = 0, room_g_up = 0, room_g_dn = 0;
+  int32_t sum_sq = 0;                  // Sum_j |p_j|^2: error of a codeword = sum_sq - its score
   if (prunable) {
     uint32_t rb_max = 0, rb_min = 0xffffffffu, g_max = 0, g_min = 0xffu;
     ICAMD_UNROLL
@@ -219,11 +227,16 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       g_min = umin(g_min, g);
     }
     const uint32_t base_rb = bch[0] | bch[2] << 16;
-    const uint32_t dev_rb = pk_max_u16(pk_subsat_u16(rb_max, base_rb), pk_subsat_u16(base_rb, rb_min));
-    const uint32_t dev_g = umax(g_max - umin(g_max, bch[1]), bch[1] - umin(bch[1], g_min));
-    dev = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
-    prunable = wave_all(dev < umin((uint32_t)kEtcA[7], room));
+    dev_rb = pk_max_u16(pk_subsat_u16(rb_max, base_rb), pk_subsat_u16(base_rb, rb_min));
+    dev_g = umax(g_max - umin(g_max, bch[1]), bch[1] - umin(bch[1], g_min));
+    room_rb_dn = base_rb;
+    room_rb_up = 0x00ff00ffu - base_rb;
+    room_g_dn = bch[1];
+    room_g_up = 255u - bch[1];
   }
+  // mid-tones everywhere in the wave: no step of any codeword is shortened, the bound is 24 (a_cw - max_c dev_c)^2
+  const bool roomy = prunable && wave_all(bmin >= (uint32_t)kEtcA[7] && bmax + (uint32_t)kEtcA[7] <= 255u);
+  const uint32_t dev_max = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
   EtcSubResult r;
   r.score = 0; r.cw = 0; r.fields = 0;
   uint32_t fast_mask = 0;  // wave-uniform: bit cw set iff that codeword took the shortcut
@@ -231,9 +244,17 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   for (int cw = 0; cw < 8; ++cw) {
     int32_t s;
     uint32_t f;
-    if (cw > 0 && prunable) {
-      const int32_t t = (int32_t)umin((uint32_t)kEtcA[cw], room) - (int32_t)dev;
+    if (cw > 0 && roomy) {
+      const int32_t t = kEtcA[cw] - (int32_t)dev_max;
       if (wave_all(t > 0 && 24 * t * t > sum_sq - r.score)) continue;
+    } else if (cw > 0 && prunable) {
+      const uint32_t a2 = (uint32_t)kEtcA[cw] * 0x00010001u;
+      const uint32_t up_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_up), dev_rb);
+      const uint32_t dn_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_dn), dev_rb);
+      const uint32_t ug = umin((uint32_t)kEtcA[cw], room_g_up), dg = umin((uint32_t)kEtcA[cw], room_g_dn);
+      const uint32_t up_g = ug - umin(ug, dev_g), dn_g = dg - umin(dg, dev_g);
+      const uint32_t lb_up = udot2_u16(up_rb, up_rb, up_g * up_g), lb_dn = udot2_u16(dn_rb, dn_rb, dn_g * dn_g);
+      if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) continue;
     }
     if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
     if (fast) {
