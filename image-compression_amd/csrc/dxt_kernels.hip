@@ -4,7 +4,7 @@
 // block row (locate_tile, ic_device.h): consecutive lanes read consecutive 16-byte (RGBA8) or 12-byte
 // (RGB888) row segments -- a wave's four row loads are 1 KiB / 768 B contiguous each -- and write
 // consecutive 8/16-byte blocks (reference raster order, internal/compressor4x4_helper.h:202-214).
-// 4.5 / 3.5 / 5 algorithmic bytes per pixel (DXT1 from RGBA8 / RGB888, DXT5) and 269 / 285 / 629 integer VALU
+// 4.5 / 3.5 / 5 algorithmic bytes per pixel (DXT1 from RGBA8 / RGB888, DXT5) and 255 / 276 / 614 integer VALU
 // instructions per block (r01): DXT1 from RGBA8 streams at the practical HBM rate, the other two are bound by
 // instruction issue (see dxt_block.h).
 #include "dxt_block.h"
