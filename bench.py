@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X block-encode backend.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W            (N > 1, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Metric (BASELINE.json): Mpixels/s DXT1 encode of 4096x4096 RGBA8 textures, inputs already resident
-in HBM, measured through the device-resident C-ABI entry point (icamd_encode_device).
+N = 1 runs in this process.  N > 1 needs one process per GPU: when the script is not already running under
+torch.distributed.run (no RANK in the environment) it re-launches itself as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+so the bare command works; launched by the driver under torch.distributed.run it just reads RANK / LOCAL_RANK /
+WORLD_SIZE.
 
-A *step* is one pass of the hot path over one batch of synthetic input: `--batch` (default 16)
-distinct 4096x4096 RGBA8 textures per rank, encoded by ONE kernel launch.  16 textures = 1 GiB of
-source per step, well past the 256 MiB Infinity Cache, so the reads really come from HBM.
-Multi-GPU (weak scaling): every rank encodes its own batch (independent textures -> no data-path
-collective; the compressed slabs stay resident in each GPU's HBM).  `--gather` additionally times one
-RCCL all-gather of the compressed output after the timed region and reports it as `gather_ms`.
+Metric (BASELINE.json): Mpixels/s DXT1 encode of 4096x4096 RGBA8 textures, inputs already resident in HBM, measured
+through the device-resident C-ABI entry point (icamd_encode_device).  `--config c2|c3|c4|c5` selects the other
+BASELINE.json configurations exactly as worded there (c2 is the default).
+
+A *step* is one pass of the hot path over one batch of synthetic input: `batch` distinct textures per rank, encoded by
+ONE kernel launch (16 x 4096^2 RGBA8 = 1 GiB of source per step, well past the 256 MiB Infinity Cache, so the reads
+really come from HBM).  Multi-GPU: every rank encodes its own textures (independent textures -> no data-path
+collective).  The timed region is exactly K such steps between barriers -> `value`.
+
+After it, for N > 1, a second region of K steps times encode -> RCCL gather of the compressed output to rank 0
+("wall time from first launch to completion of the RCCL gather on rank 0"), with the gather of batch k on
+a second stream overlapping the encode of batch k+1 -> `value_with_gather`, `gather_ms` (one un-overlapped gather).
 
 One JSON line is printed by rank 0.  Besides the driver contract it carries
-  roofline     -- algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
+  roofline     -- algorithmic bytes per launch / mean launch duration (HIP events on the launch stream); `bound` says
+                  which unit limits the kernel; `hbm_frac` and (where a matching PMC profile is committed) `valu_frac`
   cpu_baseline -- the oracle port (oracle/ic_oracle.c) timed on this host's cores on a bounded sample
+  host_api     -- the host-buffer drop-in (icamd_compress, H2D + kernel + D2H), never the reported `value`
 """
 import argparse
-import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,32 +42,75 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# integer VALU issue peak: 1 024 SIMDs x 2.4 GHz, one wave instruction per 4 clocks at the 16 lanes/clk base rate
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4.0
 
-# codec name -> (codec id, source components, swap, algorithmic bytes per pixel (read + write), label)
+# name -> (codec id, source components, algorithmic bytes per pixel (read + write), label, limiting unit)
 WORKLOADS = {
-    "dxt1_rgba8": (0, 4, 4.5, "DXT1"),
-    "dxt1_rgb888": (0, 3, 3.5, "DXT1"),
-    "dxt5_rgba8": (1, 4, 5.0, "DXT5"),
-    "etc1_rgb888": (2, 3, 3.5, "ETC1"),
-    "etc1_rgba8": (2, 4, 4.5, "ETC1"),
-    "pvrtc2_rgba8": (3, 4, 4.25, "PVRTC1-2bpp"),
+    "dxt1_rgba8": (0, 4, 4.5, "DXT1", "hbm"),
+    "dxt1_rgb888": (0, 3, 3.5, "DXT1", "hbm"),
+    "dxt5_rgba8": (1, 4, 5.0, "DXT5", "valu"),
+    "etc1_rgb888": (2, 3, 3.5, "ETC1", "valu"),
+    "etc1_rgba8": (2, 4, 4.5, "ETC1", "valu"),
+    "pvrtc2_rgba8": (3, 4, 4.25, "PVRTC1-2bpp", "valu"),
+}
+
+# BASELINE.json configs[1..4] (configs[0] is the reference's own CPU case = the cpu_baseline leg).
+#   total_textures: the configuration fixes the WHOLE job (strong scaling: split over the ranks by texture_range);
+#   batch: textures per rank per step (weak scaling)
+CONFIGS = {
+    "c2": dict(workload="dxt1_rgba8", size=4096, batch=16,
+               text="DXT1 encode 4096x4096 RGBA8 on 1x MI355X, bit-exact vs reference"),
+    "c3": dict(workload="dxt5_rgba8", size=8192, batch=4,
+               text="DXT5 (RGB+alpha) encode 8192x8192 on 1x MI355X, block-per-lane + alpha endpoint kernel"),
+    "c4": dict(workload="etc1_rgb888", size=1024, total_textures=1024, etc_strategy=2,
+               text="ETC1 high-quality search (kSmallerError), batch of 1024x 1024x1024 textures sharded across the "
+                    "GPUs (texture_range per rank, RCCL gather)"),
+    "c5": dict(workload="pvrtc2_rgba8", size=4096, batch=16,
+               text="PVRTC 2bpp encode 4096x4096 on 1x MI355X (the reference has no 4bpp mode, SURVEY D3)"),
 }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="dxt1_rgba8", choices=sorted(WORKLOADS))
-    ap.add_argument("--size", type=int, default=4096, help="texture width = height")
-    ap.add_argument("--batch", type=int, default=16, help="textures per rank per step (one launch)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json configuration preset")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--size", type=int, default=None, help="texture width = height")
+    ap.add_argument("--batch", type=int, default=None, help="textures per rank per step (one launch)")
     ap.add_argument("--content", default="noise", choices=["noise", "smooth", "flat"])
-    ap.add_argument("--etc-strategy", type=int, default=2)
-    ap.add_argument("--gather", action="store_true", help="also time one RCCL all-gather of the compressed output")
+    ap.add_argument("--etc-strategy", type=int, default=None)
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the encode->gather region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: debugging only (several ranks sharing one GPU; the gather is staged through the host)")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config or "c2"] if (args.config or not (args.workload or args.size or args.batch)) else {}
+    args.preset = (args.config or "c2") if preset else None
+    args.workload = args.workload or preset.get("workload", "dxt1_rgba8")
+    args.size = args.size or preset.get("size", 4096)
+    args.total_textures = preset.get("total_textures") if args.batch is None else None
+    args.batch = args.batch or preset.get("batch", 16)
+    if args.etc_strategy is None:
+        args.etc_strategy = preset.get("etc_strategy", 2)
+    return args
+
+
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks of this same command."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def make_batch(torch, content, batch, size, comps, device, seed):
@@ -130,129 +183,229 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
     }
 
 
+def host_api_leg(pkg, T, codec, size, strategy):
+    """Steady state of the host-buffer drop-in (Compressor::Compress, compressor.h:77-80) on ONE texture of the
+    workload's size in the reference's own input format (kRGB for DXT1 / ETC1, kRGBA for DXT5 / PVRTC)."""
+    import numpy as np
+    compressor = {0: pkg.COMPRESSOR_DXTC, 1: pkg.COMPRESSOR_DXTC, 2: pkg.COMPRESSOR_ETC, 3: pkg.COMPRESSOR_PVRTC}[codec]
+    fmt = {0: pkg.RGB, 1: pkg.RGBA, 2: pkg.RGB, 3: pkg.RGBA}[codec]
+    comps = 3 if fmt == pkg.RGB else 4
+    img = T.s_noise(size, size, comps, index=99)
+    first = pkg.compress_host(compressor, fmt, img, size, size, etc_strategy=strategy)
+    if first is None:
+        return None
+    for _ in range(2):
+        pkg.compress_host(compressor, fmt, img, size, size, etc_strategy=strategy)
+    reps = 8
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pkg.compress_host(compressor, fmt, img, size, size, etc_strategy=strategy)
+    dt = (time.perf_counter() - t0) / reps
+    want = T.oracle_compress({0: T.DXTC, 1: T.DXTC, 2: T.ETC, 3: T.PVRTC}[codec], fmt, img, size, size, 0, strategy) \
+        if size <= 4096 and codec != 2 else None
+    return {"entry_point": "icamd_compress (H2D + kernel + D2H, pageable caller buffers)", "texture": [size, size],
+            "format": "kRGB" if comps == 3 else "kRGBA", "ms_per_call": round(dt * 1e3, 4),
+            "value": round(size * size / dt / 1e6, 1), "unit": "Mpixels/s",
+            "source_GBps": round(size * size * comps / dt / 1e9, 2),
+            "parity": None if want is None else ("bit-exact vs oracle" if first == want else "MISMATCH vs oracle")}
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_distributed(args)
     import torch
     import torch.distributed as dist
     import ic_amd_loader
     pkg = ic_amd_loader.load_package()
+    from image_compression_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; using the launcher's world size" % (args.gpus, world),
+              file=sys.stderr)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the backend has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        sys.exit("bench.py: %d ranks but only %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, n_dev))
+    device = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(device)
+    distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
-    codec, comps, bytes_per_px, label = WORKLOADS[args.workload]
-    size, batch = args.size, args.batch
+    def barrier():
+        if distributed:
+            dist.barrier()
+
+    codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[args.workload]
+    size = args.size
+    if args.total_textures:  # the configuration fixes the whole job: this rank's contiguous share of it
+        t_begin, t_end = sharding.texture_range(args.total_textures, world, rank)
+        batch, scaling = t_end - t_begin, "strong"
+    else:
+        t_begin, batch, scaling = rank * args.batch, args.batch, "weak"
     src = make_batch(torch, args.content, batch, size, comps, device, seed=rank)
     per_image_out = pkg.encoded_size(codec, size, size)
-    out = torch.empty((batch, per_image_out), dtype=torch.uint8, device=device)
+    outs = [torch.empty((batch, per_image_out), dtype=torch.uint8, device=device) for _ in range(2)]
     stream = torch.cuda.current_stream()
 
-    def step():
+    def step(out):
         r = pkg.encode_device(codec, src, size, size, comps, etc_strategy=args.etc_strategy, n_images=batch, out=out,
                               stream=stream)
         assert r is not None
 
+    # ---- timed region 1 (the contract): exactly K steps of the hot path between barriers
     for _ in range(args.warmup):
-        step()
+        step(outs[0])
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         starts[i].record(stream)
-        step()
+        step(outs[0])
         ends[i].record(stream)
     torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
 
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def max_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    gather_ms = None
-    if args.gather and distributed:
-        from image_compression_amd import sharding
-        gathered = sharding.gather_output(out, world)  # warm-up (communicator set-up)
-        torch.cuda.synchronize()
-        dist.barrier()
-        g0 = time.perf_counter()
-        gathered = sharding.gather_output(out, world)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert torch.equal(gathered[rank], out)
+    def sum_over_ranks(x):
+        if not distributed:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
 
+    elapsed = max_over_ranks(elapsed)
     pixels_per_step_rank = batch * size * size
-    total_pixels = pixels_per_step_rank * world * args.steps
-    value = total_pixels / elapsed / 1e6
+    pixels_per_step_all = sum_over_ranks(float(pixels_per_step_rank))
+    value = pixels_per_step_all * args.steps / elapsed / 1e6
 
+    # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
+    gather = None
+    if distributed and not args.no_gather:
+        counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
+            else [(r * batch, (r + 1) * batch) for r in range(world)]
+        counts = [e - b for b, e in counts]
+        comm = torch.cuda.Stream(device=device)
+        gathered = [sharding.alloc_gather_buffers(outs[0], counts, rank) for _ in range(2)]
+        enc_done = [torch.cuda.Event() for _ in range(2)]
+        gat_done = [torch.cuda.Event() for _ in range(2)]
+
+        def gather_async(slot):
+            enc_done[slot].record(stream)
+            with torch.cuda.stream(comm):
+                comm.wait_event(enc_done[slot])
+                sharding.gather_to_root(outs[slot], gathered[slot], counts, rank, host_staged=args.backend == "gloo")
+                gat_done[slot].record(comm)
+
+        for slot in range(2):  # warm-up: communicator set-up, both buffers touched
+            step(outs[slot])
+            gather_async(slot)
+        torch.cuda.synchronize()
+        barrier()
+        g0 = time.perf_counter()
+        gather_async(0)
+        torch.cuda.synchronize()
+        barrier()
+        gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            slot = i & 1
+            stream.wait_event(gat_done[slot])  # the gather that last read this output buffer has finished
+            step(outs[slot])
+            gather_async(slot)                 # ... overlaps the encode of the next batch
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed_g = max_over_ranks(time.perf_counter() - t1)
+        ok = True
+        if rank == 0:
+            last = gathered[(args.steps - 1) & 1]
+            ok = bool(torch.equal(last[0], outs[(args.steps - 1) & 1]))
+        out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
+        gather = {"value_with_gather": round(pixels_per_step_all * args.steps / elapsed_g / 1e6, 1),
+                  "ms_per_step_with_gather": round(elapsed_g / args.steps * 1e3, 4),
+                  "gather_ms": round(gather_ms, 4),
+                  "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
+                  "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, "
+                            "overlapping the next batch's encode (backend %s)" % args.backend,
+                  "rank0_copy_matches": ok}
+
+    tex = "%dx%d %s" % (size, size, "RGBA8" if comps == 4 else "RGB888")
     result = {
-        "metric": "Mpixels/s encode (%s, %dx%d %s)" % (label, size, size, "RGBA8" if comps == 4 else "RGB888"),
+        "metric": "Mpixels/s encode (%s, %s)" % (label, tex),
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic (%s, seeded, generated on device)" % args.content,
-        "config": {"workload": "%s encode of %d x %dx%d %s textures per GPU per step (one launch), device-resident"
-                               % (label, batch, size, size, "RGBA8" if comps == 4 else "RGB888"),
-                   "codec": args.workload, "textures_per_gpu_per_step": batch, "texture": [size, size],
-                   "src_bytes_per_pixel": comps, "etc_strategy": args.etc_strategy if codec == 2 else None,
-                   "parallelism": "independent textures per GPU (no data-path collective)",
+        "config": {"workload": ("BASELINE config %s: %s; " % (args.preset, CONFIGS[args.preset]["text"]) if args.preset else "")
+                               + "%s encode of %d x %s textures per GPU per step (one launch), device-resident"
+                               % (label, batch, tex),
+                   "preset": args.preset, "codec": args.workload, "textures_per_gpu_per_step": batch,
+                   "textures_per_step_all_gpus": int(round(pixels_per_step_all / (size * size))),
+                   "texture": [size, size], "src_bytes_per_pixel": comps,
+                   "etc_strategy": args.etc_strategy if codec == 2 else None,
+                   "parallelism": "independent textures per GPU, texture_range per rank (no data-path collective)",
                    "kernel": pkg.kernel_name(codec, comps)},
     }
-    if gather_ms is not None:
-        result["gather_ms"] = round(gather_ms, 3)
+    if gather is not None:
+        result.update(gather)
 
     if rank == 0:
         algo_bytes = pixels_per_step_rank * bytes_per_px
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (size, batch) == (4096, 16):
             with open(tpath) as f:
                 traffic = json.load(f).get(args.workload)
+        hbm_frac = round(achieved / HBM_PEAK_GBPS, 4)
         result["roofline"] = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "bound": limiting_unit, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": hbm_frac, "hbm_frac": hbm_frac, "valu_frac": None, "traffic": traffic,
             "kernel": pkg.kernel_name(codec, comps), "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_pixel": bytes_per_px, "algorithmic_bytes_per_launch": int(algo_bytes),
             "read_roofline_frac": round((pixels_per_step_rank * comps / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS, 4),
         }
-        # Informational: how busy the integer VALU is.  Instructions per wave come from the committed PMC profile of
-        # this workload (SQ_INSTS_VALU / SQ_WAVES); a wave instruction occupies its SIMD for 4 clocks at the 16
-        # lanes/clk base rate, 1 024 SIMDs, 2.4 GHz.  Not a second roofline in the contract's sense.
-        spath = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % args.workload)
-        if os.path.exists(spath) and (size, batch) == (4096, 16):
-            with open(spath) as f:
-                kernels = json.load(f).get("kernels", {})
-            issue_s = 0.0
-            for kinfo in kernels.values():
-                if "valu_insts_per_wave" in kinfo and "SQ_WAVES" in kinfo:
-                    issue_s += kinfo["SQ_WAVES"] * kinfo["valu_insts_per_wave"] * 4.0 / (1024 * 2.4e9)
-            if issue_s > 0:
-                result["roofline"]["valu_issue_frac"] = round(issue_s / (kernel_ms * 1e-3), 3)
+        # VALU issue fraction: executed wave-level VALU instructions per Mpixel from the committed PMC profile of
+        # EXACTLY this workload / content / strategy (profiles/valu_insts.json, written by scripts/summarize_profiles.py
+        # from SQ_INSTS_VALU), against 1 024 SIMDs x 2.4 GHz / 4 clk.  Omitted when no matching profile exists.
+        vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+        if os.path.exists(vpath):
+            with open(vpath) as f:
+                vi = json.load(f).get("%s/%s/s%d" % (args.workload, args.content, args.etc_strategy if codec == 2 else 0))
+            if vi:
+                insts = vi["valu_wave_insts_per_Mpixel"] * pixels_per_step_rank / 1e6
+                result["roofline"]["valu_frac"] = round(insts / VALU_PEAK_WAVE_INSTS / (kernel_ms * 1e-3), 3)
+                result["roofline"]["valu_wave_insts_per_block"] = vi.get("valu_wave_insts_per_block_lane")
+                result["roofline"]["valu_profile"] = vi.get("profile")
         import ic_testlib as T
         host0 = src[0].cpu().numpy()
         if not args.no_verify:
-            got = out[0].cpu().numpy().tobytes()
+            got = outs[0][0].cpu().numpy().tobytes()
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
             want = T.oracle_encode(codec, host0, size, size, comps, 0, args.etc_strategy,
                                    threads=1 if codec == 3 else cores)
@@ -260,19 +413,23 @@ def main():
             if got != want:
                 print(json.dumps(result))
                 sys.exit("parity check failed")
-            if codec != 3:
-                # informational: quality of the encoded texture 0, decoded again on the device
-                try:
-                    dec = pkg.decode_device(codec, out[0].contiguous(), size, size)
-                    dcomps = 4 if codec == 1 else 3
-                    a = dec.view(size, size, dcomps).to(torch.float64)
-                    b = src[0][..., :dcomps].to(torch.float64)
-                    mse = float(((a - b) ** 2).mean())
-                    result["psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
-                except Exception as e:  # never let the informational figure take the benchmark line down
-                    result["psnr_db"] = "unavailable: %s" % e
+            # informational: quality of the encoded texture 0, decoded again on the device
+            try:
+                dec = pkg.decode_device(codec, outs[0][0].contiguous(), size, size)
+                dcomps = 4 if codec in (1, 3) else 3
+                a = dec.view(size, size, dcomps).to(torch.float64)
+                b = src[0][..., :dcomps].to(torch.float64)
+                mse = float(((a - b) ** 2).mean())
+                result["psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
+            except Exception as e:  # never let the informational figure take the benchmark line down
+                result["psnr_db"] = "unavailable: %s" % e
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(T, codec, comps, size, args.etc_strategy, host0)
+        if not args.no_host_api and world == 1:
+            try:
+                result["host_api"] = host_api_leg(pkg, T, codec, size, args.etc_strategy)
+            except Exception as e:
+                result["host_api"] = "unavailable: %s" % e
         print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -56,13 +56,6 @@ ICAMD_DEV uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
 }
 #endif
 
-// True iff the predicate holds in every active lane of the wave (the emulation has one "lane").
-#if defined(ICAMD_HOST_EMULATION)
-ICAMD_DEV bool wave_all(bool p) { return p; }
-#else
-ICAMD_DEV bool wave_all(bool p) { return __all(p ? 1 : 0) != 0; }
-#endif
-
 // ETC1 modifier table (OES_compressed_ETC1_RGB8_texture; etc.cc:101-110): row cw = {a, b, -a, -b}.
 // Packed as bytes so a per-lane codeword can look its row up with two v_bfe.
 constexpr uint32_t kEtcModA_lo = 2u | 5u << 8 | 9u << 16 | 13u << 24;

@@ -143,6 +143,13 @@ ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return max(a, b); }
 
 #endif
 
+// True iff the predicate holds in every active lane of the wave (the emulation has one "lane").
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV bool wave_all(bool p) { return p; }
+#else
+ICAMD_DEV bool wave_all(bool p) { return __all(p ? 1 : 0) != 0; }
+#endif
+
 // Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV uint32_t opaque(uint32_t v) { return v; }

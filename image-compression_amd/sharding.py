@@ -63,9 +63,17 @@ def pvrtc_region(size, world_size, rank):
             "blocks_h": 1 << (m - m // 2)}
 
 
+def _global_rank(group, group_rank):
+    """torch.distributed addresses peers (dst= / src=) by GLOBAL rank, even inside a sub-group."""
+    if group is None or group is dist.group.WORLD:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
 def gather_output(local, world_size, dst=None, group=None):
     """Gathers equally sized per-rank compressed buffers.  dst=None: all-gather (every rank gets
-    [world, ...]); dst=r: only rank r receives (others get None).  One collective, after the encode."""
+    [world, ...]); dst=r (a rank of `group`): only that rank receives (others get None).  One collective, after the
+    encode."""
     if world_size == 1:
         return local.unsqueeze(0)
     if dst is None:
@@ -74,10 +82,57 @@ def gather_output(local, world_size, dst=None, group=None):
                            device=local.device)  # concatenation along dim 0: the layout both RCCL and gloo accept
         dist.all_gather_into_tensor(flat, local, group=group)
         return flat.view((world_size,) + tuple(local.shape))
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)  # rank inside `group`, the space `dst` is given in
     bufs = [torch.empty_like(local) for _ in range(world_size)] if rank == dst else None
-    dist.gather(local.contiguous(), bufs, dst=dst, group=group)
+    dist.gather(local.contiguous(), bufs, dst=_global_rank(group, dst), group=group)
     return torch.stack(bufs) if rank == dst else None
+
+
+def alloc_gather_buffers(local, counts, rank, dst=0):
+    """Receive buffers on `dst` for gather_to_root: one [counts[r], ...] tensor per rank (None elsewhere)."""
+    if rank != dst:
+        return None
+    return [torch.empty((c,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for c in counts]
+
+
+def gather_to_root(local, bufs, counts, rank, dst=0, group=None, host_staged=False):
+    """Gathers per-rank compressed slabs (rank r holds counts[r] textures' worth of blocks) into `bufs` on rank `dst`
+    (ranks of `group`).  Enqueued on the CURRENT stream and not synchronised, so the caller can run it on a side
+    stream underneath the next batch's encode.  Equal counts: one dist.gather (RCCL: grouped send/recv over the xGMI
+    links, every peer writes its own slab of rank 0's HBM).  Unequal counts (n_textures % world != 0): batched
+    point-to-point.  host_staged: the gloo debugging path (device tensors staged through host memory)."""
+    world = len(counts)
+    if world == 1:
+        bufs[0].copy_(local)
+        return
+    gdst = _global_rank(group, dst)
+    if host_staged:
+        h = local.cpu()
+        hb = [torch.empty((c,) + tuple(local.shape[1:]), dtype=local.dtype) for c in counts] if rank == dst else None
+        if len(set(counts)) == 1:
+            dist.gather(h, hb, dst=gdst, group=group)
+        else:
+            _p2p_gather(h, hb, counts, rank, dst, group)
+        if rank == dst:
+            for b, x in zip(bufs, hb):
+                b.copy_(x)
+        return
+    if len(set(counts)) == 1:
+        dist.gather(local.contiguous(), bufs if rank == dst else None, dst=gdst, group=group)
+    else:
+        _p2p_gather(local.contiguous(), bufs, counts, rank, dst, group)
+
+
+def _p2p_gather(local, bufs, counts, rank, dst, group):
+    if rank == dst:
+        bufs[dst].copy_(local)
+        ops = [dist.P2POp(dist.irecv, bufs[r], _global_rank(group, r), group) for r in range(len(counts))
+               if r != dst and counts[r] > 0]
+    else:
+        ops = [dist.P2POp(dist.isend, local, _global_rank(group, dst), group)] if counts[rank] > 0 else []
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
 
 
 def encode_batch_sharded(encode_fn, textures, world_size, rank, gather_dst=None, gather=True):

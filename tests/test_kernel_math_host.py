@@ -165,3 +165,53 @@ def test_random_soak_host_emulation(emul):
             (codec, comps, swap, strategy, h, w, pad)
         n += 1
     assert n == 140
+
+
+def _alpha_blocks_exhaustive():
+    """Alpha values of 4x4 blocks that drive ComputeAlphaBits (dxtc.cc:427-479) through every (alpha0, alpha1, alpha)
+    it can see: 8-value mode = exactly one pixel each at the maximum and the minimum and every value in between;
+    6-value mode = two zeros and / or two 255s next to a non-extreme range [lo, hi] and every value inside it."""
+    rows = []
+    for a0 in range(1, 256):            # 8-value mode: a0 > a1, the extremes appear once (incl. 0 and 255)
+        for a1 in range(0, a0):
+            inner = list(range(a1 + 1, a0))
+            fill = (a0 + a1) // 2 if inner else (a0 if a0 < 255 else a1)
+            if not inner and fill in (0, 255):
+                continue                # (255, 254 .. 0): no non-extreme filler exists that keeps the mode
+            for i in range(0, max(len(inner), 1), 14):
+                rows.append(([a0, a1] + inner[i:i + 14] + [fill] * 14)[:16])
+    for lo in range(1, 255):            # 6-value mode: a0 = lo <= a1 = hi, specials 0 / 255 present
+        for hi in range(lo, 255):
+            inner = list(range(lo, hi + 1))
+            for specials in ([0, 0], [255, 255], [0, 0, 255], [0, 255, 255]):
+                room = 16 - len(specials) - 2
+                for i in range(0, len(inner), room):
+                    rows.append(([lo, hi] + specials + inner[i:i + room] + [lo] * room)[:16])
+    for v in range(256):                # all equal; only extremes (the (0, 255) reset, dxtc.cc:400-403)
+        rows.append([v] * 16)
+        rows.append([0] * (v % 15 + 1) + [255] * (15 - v % 15))
+    return np.asarray(rows, np.uint8)
+
+
+def test_dxt5_alpha_index_search_exhaustive(emul):
+    """The O(1) alpha index search (dxt_block.h + the generated dxt5_alpha_index_table.inc) against the oracle's
+    8-candidate scan for every (alpha0, alpha1, alpha) of both modes -- about 1.3 M blocks."""
+    alphas = _alpha_blocks_exhaustive()
+    g = np.random.Generator(np.random.PCG64(5))
+    n = alphas.shape[0]
+    perm = np.argsort(g.random((n, 16)), axis=1)          # shuffle pixel positions inside each block
+    alphas = np.take_along_axis(alphas, perm, axis=1)
+    chunk = 1 << 16
+    for s in range(0, n, chunk):
+        a = alphas[s:s + chunk]
+        m = a.shape[0]
+        img = np.zeros((4, 4 * m, 4), np.uint8)
+        img[..., :3] = g.integers(0, 256, (4, 4 * m, 3), dtype=np.uint8)
+        img[..., 3] = a.reshape(m, 4, 4).transpose(1, 0, 2).reshape(4, 4 * m)
+        want = T.oracle_encode(T.DXT5, img, 4, 4 * m, 4)
+        got = emul_encode(emul, T.DXT5, img, 4, 4 * m, 4)
+        if got != want:
+            w_ = np.frombuffer(want, np.uint8).reshape(m, 16)[:, :8]
+            g_ = np.frombuffer(got, np.uint8).reshape(m, 16)[:, :8]
+            bad = np.nonzero((w_ != g_).any(axis=1))[0][:5]
+            raise AssertionError([(a[i].tolist(), w_[i].tolist(), g_[i].tolist()) for i in bad])

@@ -67,6 +67,32 @@ def _worker(rank, world, port, results):
     ok &= slab == whole[geo["dst_offset_bytes"]: geo["dst_offset_bytes"] + geo["dst_bytes"]]
     sizes = [sh.slab_geometry(h, w, comps, stride, 16, world, r)["dst_bytes"] for r in range(world)]
     ok &= sum(sizes) == len(whole)
+    # (3) gather_to_root: config 4's texture_range split, equal and unequal per-rank counts, rank-0 receive buffers
+    for n in (8, 7):
+        counts = [e - b for b, e in (sh.texture_range(n, world, r) for r in range(world))]
+        b, e = sh.texture_range(n, world, rank)
+        full = torch.arange(n * 5, dtype=torch.uint8).reshape(n, 5)
+        local = full[b:e].clone()
+        bufs = sh.alloc_gather_buffers(local, counts, rank)
+        sh.gather_to_root(local, bufs, counts, rank)
+        if rank == 0:
+            ok &= bool(torch.equal(torch.cat(bufs), full))
+        else:
+            ok &= bufs is None
+        # the debugging path bench.py uses when several ranks share one GPU
+        bufs = sh.alloc_gather_buffers(local, counts, rank)
+        sh.gather_to_root(local, bufs, counts, rank, host_staged=True)
+        if rank == 0:
+            ok &= bool(torch.equal(torch.cat(bufs), full))
+    # (4) gather_output inside a sub-group whose root is not global rank 0 (group ranks != global ranks)
+    sub = dist.new_group(ranks=list(range(world))[::-1])  # group rank g <-> global rank world-1-g
+    local = torch.full((3,), rank, dtype=torch.uint8)
+    got = sh.gather_output(local, world, dst=0, group=sub)
+    if dist.get_rank(sub) == 0:
+        want = torch.stack([torch.full((3,), dist.get_global_rank(sub, g), dtype=torch.uint8) for g in range(world)])
+        ok &= got is not None and bool(torch.equal(got, want))
+    else:
+        ok &= got is None
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     results[rank] = int(flag.item())
