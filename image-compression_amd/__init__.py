@@ -27,7 +27,8 @@ EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
+    "icamd_pvrtc2_set_workspace", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -81,6 +82,11 @@ def lib():
         L.icamd_compress_batch.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp, _ci, _vp]
         L.icamd_pvrtc2_encode_region_device.restype = _ci
         L.icamd_pvrtc2_encode_region_device.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp]
+        if "ICAMD_LIB_PATH" not in os.environ or hasattr(L, "icamd_pvrtc2_workspace_size"):  # older A/B builds lack it
+            L.icamd_pvrtc2_workspace_size.restype = _sz
+            L.icamd_pvrtc2_workspace_size.argtypes = [_u32, _u32]
+            L.icamd_pvrtc2_set_workspace.restype = _ci
+            L.icamd_pvrtc2_set_workspace.argtypes = [_vp, _sz]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -240,6 +246,20 @@ def pvrtc_encode_region_device(src, size, first_block, n_blocks, *, out=None, st
     if not _check(st, "icamd_pvrtc2_encode_region_device"):
         return None
     return out
+
+
+def pvrtc_workspace_size(size, n_images=1):
+    return lib().icamd_pvrtc2_workspace_size(size, n_images)
+
+
+def pvrtc_set_workspace(workspace):
+    """Caller-owned PVRTC scratch for the calls that follow on this thread (a torch.uint8 CUDA tensor of at least
+    pvrtc_workspace_size bytes; needed to capture PVRTC launches into a HIP graph).  None: the library's own buffer."""
+    if workspace is None:
+        return _check(lib().icamd_pvrtc2_set_workspace(None, 0), "icamd_pvrtc2_set_workspace")
+    assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous()
+    return _check(lib().icamd_pvrtc2_set_workspace(ctypes.c_void_p(workspace.data_ptr()), workspace.numel()),
+                  "icamd_pvrtc2_set_workspace")
 
 
 def compress_batch_host(compressor, fmt, images, height, width, devices, *, padding_bytes_per_row=0,

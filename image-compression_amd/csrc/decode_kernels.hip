@@ -17,11 +17,11 @@ __device__ __forceinline__ void decode_one(const DecodeParams &P, uint32_t k) {
   uint32_t px[16];
   const bool swap = P.swap_rb != 0;
   if (CODEC == ICAMD_DXT5) {
-    const uint4 w = *reinterpret_cast<const uint4 *>(src);
+    const U4 w = *reinterpret_cast<const U4 *>(src);  // no alignment assumed: the caller owns the block pointer
     decode_dxt_colors(w.z, w.w, swap, true, px);
     decode_dxt5_alpha(w.x, w.y, px);
   } else {
-    const uint2 w = *reinterpret_cast<const uint2 *>(src);
+    const U2 w = *reinterpret_cast<const U2 *>(src);
     if (CODEC == ICAMD_DXT1) decode_dxt_colors(w.x, w.y, swap, false, px);
     else decode_etc1(w.x, w.y, px);
   }
@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_decode_kernel
 
 hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
   if (P.total_blocks == 0) return hipSuccess;
+  (void)hipGetLastError();  // a stale error of another library on this thread is not this launch's
   const dim3 grid((P.total_blocks + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_dxt1_decode_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_dxt5_decode_kernel, grid, block, 0, stream, P);

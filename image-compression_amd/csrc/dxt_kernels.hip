@@ -54,7 +54,6 @@ const char *dxt_kernel_name(int codec, int comps) {
 }
 
 hipError_t launch_dxt(int codec, int comps, const GridParams &P, hipStream_t stream) {
-  if (P.total_blocks == 0) return hipSuccess;
   if (codec == ICAMD_DXT5) {
     if (comps != 4) return hipErrorInvalidValue;
     return launch_tiled(icamd_dxt5_rgba8_kernel, icamd_dxt5_rgba8_narrow_kernel, P, stream);

@@ -27,7 +27,6 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(
 const char *etc1_kernel_name(int comps) { return comps == 4 ? "icamd_etc1_rgba8_kernel" : "icamd_etc1_rgb888_kernel"; }
 
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
-  if (P.total_blocks == 0) return hipSuccess;
   // 16 x 16-block tiles (a wave = 16 x 4 blocks = 64 x 16 pixels) instead of 256 x 1: the encoder's wave-uniform
   // decisions (unclamped shortcut, codeword pruning) fire far more often on compact waves, and at 7 % of the HBM
   // roofline the narrower loads cost nothing: noise 1.47 = 1.47 ms, smooth 1.85 -> 1.61 ms, flat 1.90 -> 1.72 ms (r01)

@@ -239,6 +239,9 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
     // preconditions of PvrtcCompressor::Compress, pvrtc.cc:636-650 (source always read as RGBA8888)
     if (!is_pow2(width) || !is_pow2(height) || width != height || width % 8 || height % 4) return ICAMD_FALSE;
     if (src_components != 4 || row_stride_bytes != width * 4u) return ICAMD_FALSE;
+    if (reinterpret_cast<uintptr_t>(d_src) % 16u || reinterpret_cast<uintptr_t>(d_dst) % 8u ||
+        (n_images > 1 && (src_image_stride_bytes % 16u || dst_image_stride_bytes % 8u)))
+      return fail(ICAMD_ERR_ARG, "PVRTC: source must be 16-byte aligned, output 8-byte aligned");
     icamd::PvrtcParams P;
     P.src = static_cast<const uint8_t *>(d_src);
     P.dst = static_cast<uint8_t *>(d_dst);
@@ -264,15 +267,10 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
   P.block_rows = num_blocks4(std::max(height, grid_height));  // helper.h:487-488,501-502
   P.block_cols = num_blocks4(std::max(width, grid_width));
   P.row_stride = row_stride_bytes;
-  const uint64_t bpi = (uint64_t)P.block_rows * P.block_cols;
-  const uint64_t total = bpi * n_images;
-  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
-  P.blocks_per_image = (uint32_t)bpi;
-  P.total_blocks = (uint32_t)total;
+  P.n_images = n_images;
   P.swap_rb = swap_rb ? 1u : 0u;
   P.etc_strategy = (uint32_t)etc_strategy;
-  P.div_bpi = icamd::make_fastdiv(P.blocks_per_image);
-  P.div_cols = icamd::make_fastdiv(P.block_cols);
+  P.log2_tile_cols = P.tile_row0 = P.force_gather = 0;
   if (codec == ICAMD_ETC1)
     ICAMD_HIP(icamd::launch_etc1(src_components, P, stream), "launch etc1");
   else
@@ -287,6 +285,8 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
   const uint64_t blocks = (uint64_t)(size / 8) * (size / 4);
   if (!is_pow2(n_blocks) || (first_block & (n_blocks - 1u)) != 0 || (uint64_t)first_block + n_blocks > blocks)
     return fail(ICAMD_ERR_ARG, "PVRTC region must be a power-of-two, aligned range of the image's blocks");
+  if (reinterpret_cast<uintptr_t>(d_src) % 16u || reinterpret_cast<uintptr_t>(d_dst_region) % 8u)
+    return fail(ICAMD_ERR_ARG, "PVRTC: source must be 16-byte aligned, output 8-byte aligned");
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   icamd::PvrtcParams P;
@@ -299,6 +299,17 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
   P.region_first = first_block;
   P.region_blocks = n_blocks;
   ICAMD_HIP(icamd::launch_pvrtc2(P, static_cast<hipStream_t>(hip_stream)), "launch pvrtc2 region");
+  return ICAMD_OK;
+}
+
+size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images) {
+  if (!is_pow2(size) || size < 8) return 0;
+  return icamd::pvrtc2_workspace_bytes(size, n_images);
+}
+
+int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
+  if (d_workspace && reinterpret_cast<uintptr_t>(d_workspace) % 8u) return fail(ICAMD_ERR_ARG, "workspace must be 8-byte aligned");
+  icamd::pvrtc2_set_workspace(d_workspace, bytes);
   return ICAMD_OK;
 }
 
@@ -392,6 +403,29 @@ int icamd_compress_and_pad(int compressor, int etc_strategy, int format, uint32_
                               padded_width, padding_bytes_per_row, buffer, out, out_size);
 }
 
+// One launch: fewer than 2^31 blocks (the decode kernels index blocks with 32 bits).
+static int decode_launch(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t row_stride,
+                         uint32_t n_images, size_t src_image_stride, size_t dst_image_stride, const uint8_t *blocks,
+                         uint8_t *pixels, hipStream_t stream) {
+  icamd::DecodeParams P;
+  P.blocks = blocks;
+  P.pixels = pixels;
+  P.src_image_stride = src_image_stride;
+  P.dst_image_stride = dst_image_stride;
+  P.height = height;
+  P.width = width;
+  P.block_rows = num_blocks4(height);
+  P.block_cols = num_blocks4(width);
+  P.row_stride = row_stride;
+  P.blocks_per_image = P.block_rows * P.block_cols;
+  P.total_blocks = P.blocks_per_image * n_images;
+  P.swap_rb = swap_rb ? 1u : 0u;
+  P.div_bpi = icamd::make_fastdiv(P.blocks_per_image);
+  P.div_cols = icamd::make_fastdiv(P.block_cols);
+  ICAMD_HIP(icamd::launch_decode(codec, P, stream), "launch decode");
+  return ICAMD_OK;
+}
+
 int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                         uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
                         const void *d_blocks, void *d_pixels, void *hip_stream) {
@@ -400,24 +434,34 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  icamd::DecodeParams P;
-  P.blocks = static_cast<const uint8_t *>(d_blocks);
-  P.pixels = static_cast<uint8_t *>(d_pixels);
-  P.src_image_stride = src_image_stride_bytes;
-  P.dst_image_stride = dst_image_stride_bytes;
-  P.height = height;
-  P.width = width;
-  P.block_rows = num_blocks4(height);
-  P.block_cols = num_blocks4(width);
-  P.row_stride = width * (codec == ICAMD_DXT5 ? 4u : 3u) + padding_bytes_per_row;
-  const uint64_t bpi = (uint64_t)P.block_rows * P.block_cols, total = bpi * n_images;
-  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
-  P.blocks_per_image = (uint32_t)bpi;
-  P.total_blocks = (uint32_t)total;
-  P.swap_rb = swap_rb ? 1u : 0u;
-  P.div_bpi = icamd::make_fastdiv(P.blocks_per_image);
-  P.div_cols = icamd::make_fastdiv(P.block_cols);
-  ICAMD_HIP(icamd::launch_decode(codec, P, static_cast<hipStream_t>(hip_stream)), "launch decode");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const uint8_t *blocks = static_cast<const uint8_t *>(d_blocks);
+  uint8_t *pixels = static_cast<uint8_t *>(d_pixels);
+  const uint32_t block_bytes = codec == ICAMD_DXT5 ? 16u : 8u;
+  const uint32_t row_stride = width * (codec == ICAMD_DXT5 ? 4u : 3u) + padding_bytes_per_row;
+  const uint64_t block_cols = num_blocks4(width), bpi = (uint64_t)num_blocks4(height) * block_cols;
+  const uint64_t kMaxBlocks = (1ull << 31) - 1;
+  if (bpi <= kMaxBlocks) {  // whole images, as many per launch as the 32-bit block index allows
+    const uint64_t per_launch = std::max<uint64_t>(1, kMaxBlocks / bpi);
+    for (uint64_t first = 0; first < n_images; first += per_launch) {
+      const uint32_t count = (uint32_t)std::min<uint64_t>(per_launch, n_images - first);
+      rc = decode_launch(codec, swap_rb, height, width, row_stride, count, src_image_stride_bytes,
+                         dst_image_stride_bytes, blocks + first * src_image_stride_bytes,
+                         pixels + first * dst_image_stride_bytes, stream);
+      if (rc != ICAMD_OK) return rc;
+    }
+    return ICAMD_OK;
+  }
+  // a single image of 2^31 blocks or more: bands of block rows (blocks are row-major, helper.h:218-262)
+  const uint32_t band = (uint32_t)(kMaxBlocks / block_cols);
+  for (uint32_t i = 0; i < n_images; ++i)
+    for (uint64_t r0 = 0; r0 < num_blocks4(height); r0 += band) {
+      const uint32_t rows = (uint32_t)std::min<uint64_t>((uint64_t)band * 4u, (uint64_t)height - r0 * 4u);
+      rc = decode_launch(codec, swap_rb, rows, width, row_stride, 1, 0, 0,
+                         blocks + i * src_image_stride_bytes + r0 * block_cols * block_bytes,
+                         pixels + i * dst_image_stride_bytes + r0 * 4u * row_stride, stream);
+      if (rc != ICAMD_OK) return rc;
+    }
   return ICAMD_OK;
 }
 
@@ -454,6 +498,8 @@ int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, 
                      uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) {
   int codec;
   if (!d_blocks || !d_out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
   icamd::BlockOpParams P;
   P.in_rows = num_blocks4(ch); P.in_cols = num_blocks4(cw);
   P.out_rows = num_blocks4(ph); P.out_cols = num_blocks4(pw);
@@ -477,6 +523,8 @@ int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32
                             const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) {
   int codec;
   if (!d_blocks || !d_out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
   icamd::BlockOpParams P;
   P.in_rows = num_blocks4(uh); P.in_cols = num_blocks4(uw);
   // helper.h:281-284, :340-341
@@ -501,12 +549,16 @@ int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32
 
 int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream) {
   if (!d_blocks) return ICAMD_FALSE;
-  if (n_bytes / 8 >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
+  if (reinterpret_cast<uintptr_t>(d_blocks) % 8u) return fail(ICAMD_ERR_ARG, "block pointer must be 8-byte aligned");
   if (n_bytes < 8) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  ICAMD_HIP(icamd::launch_transcode_dxt1_to_etc1(d_blocks, (uint32_t)(n_bytes / 8), static_cast<hipStream_t>(hip_stream)),
-            "launch transcode");
+  const size_t kChunk = (size_t)1 << 30;  // blocks per launch (32-bit block index in the kernel)
+  for (size_t first = 0; first < n_bytes / 8; first += kChunk) {
+    const size_t count = std::min(kChunk, n_bytes / 8 - first);
+    ICAMD_HIP(icamd::launch_transcode_dxt1_to_etc1(static_cast<uint8_t *>(d_blocks) + first * 8, (uint32_t)count,
+                                                   static_cast<hipStream_t>(hip_stream)), "launch transcode");
+  }
   return ICAMD_OK;
 }
 

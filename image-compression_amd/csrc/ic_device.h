@@ -58,12 +58,12 @@ struct GridParams {
   uint32_t height, width;          // source image (pixels)
   uint32_t block_rows, block_cols; // emitted block grid (>= image for CompressAndPad)
   uint32_t row_stride;             // bytes between source rows
-  uint32_t blocks_per_image;
-  uint32_t total_blocks;           // blocks_per_image * n_images
+  uint32_t n_images;
   uint32_t swap_rb;                // source is B,G,R(,A)
   uint32_t etc_strategy;
   uint32_t log2_tile_cols;         // a workgroup covers 2^log2_tile_cols x (256 >> log2_tile_cols) blocks
-  FastDiv div_bpi, div_cols;
+  uint32_t tile_row0;              // first tile row of this launch (grids of more than 65 535 tile rows are chunked)
+  uint32_t force_gather;           // rows too long for 32-bit lane offsets: every block takes the 64-bit gather path
 };
 
 // ---- thin wrappers over the gfx950 instructions the kernels rely on ----
@@ -203,14 +203,6 @@ ICAMD_DEV void store_stream16(void *p, uint32_t a, uint32_t b, uint32_t c, uint3
 }
 #endif
 
-// Decompose a global block id into (image, block_row, block_col).
-ICAMD_DEV void locate_block(const GridParams &P, uint32_t k, uint32_t &img, uint32_t &brow, uint32_t &bcol) {
-  img = fastdiv(k, P.div_bpi);
-  uint32_t rem = k - img * P.blocks_per_image;
-  brow = fastdiv(rem, P.div_cols);
-  bcol = rem - brow * P.block_cols;
-}
-
 #if !defined(ICAMD_HOST_EMULATION)
 // Launch geometry of the encoders: grid = (column tiles, row tiles, images), one workgroup per tile of
 // 2^log2_tile_cols x (256 >> log2_tile_cols) blocks (256 x 1 for images at least 1024 pixels wide).  Image, tile row
@@ -234,7 +226,7 @@ __device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
   t.lx = WIDE ? threadIdx.x : threadIdx.x & (cols - 1u);
   t.ly = WIDE ? 0u : threadIdx.x >> P.log2_tile_cols;
   t.bcol0 = blockIdx.x * cols;
-  t.brow0 = blockIdx.y * rows;
+  t.brow0 = (blockIdx.y + P.tile_row0) * rows;
   t.bcol = t.bcol0 + t.lx;
   t.brow = t.brow0 + t.ly;
   t.img = blockIdx.z;
@@ -293,10 +285,11 @@ ICAMD_DEV void load_block_interior(const uint8_t *__restrict__ base, uint32_t of
   }
 }
 
+// wide_ok = false: rows too long for the interior path's 32-bit row offsets -- gather every pixel with 64-bit addresses.
 template <int COMPS>
 ICAMD_DEV void load_block(const uint8_t *__restrict__ img, uint32_t h, uint32_t w, uint32_t stride,
-                          uint32_t row, uint32_t col, uint32_t px[16]) {
-  if (row + 4 <= h && col + 4 <= w) {
+                          uint32_t row, uint32_t col, uint32_t px[16], bool wide_ok = true) {
+  if (wide_ok && row + 4 <= h && col + 4 <= w) {
     load_block_interior<COMPS>(img + (size_t)row * stride + (size_t)col * COMPS, 0u, stride, px);
   } else {
     ICAMD_UNROLL
@@ -317,12 +310,12 @@ ICAMD_DEV void load_block(const uint8_t *__restrict__ img, uint32_t h, uint32_t 
 #if !defined(ICAMD_HOST_EMULATION)
 template <int COMPS>
 __device__ __forceinline__ void load_tile_block(const GridParams &P, const TileCoord &t, uint32_t px[16]) {
-  if (t.interior || (t.brow * 4u + 4u <= P.height && t.bcol * 4u + 4u <= P.width)) {
+  if (!P.force_gather && (t.interior || (t.brow * 4u + 4u <= P.height && t.bcol * 4u + 4u <= P.width))) {
     const TileSrc ts = tile_src<COMPS>(P, t);
     load_block_interior<COMPS>(ts.base, ts.off, P.row_stride, px);
   } else {
     load_block<COMPS>(P.src + (size_t)t.img * P.src_image_stride, P.height, P.width, P.row_stride, t.brow * 4u,
-                      t.bcol * 4u, px);
+                      t.bcol * 4u, px, !P.force_gather);
   }
 }
 #endif

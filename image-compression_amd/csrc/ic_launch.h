@@ -18,28 +18,37 @@ inline uint32_t tile_log2_cols(uint32_t block_cols) {
   while (l < 8 && (1u << l) < block_cols) ++l;
   return l;
 }
-// Launches `kernel` over every tile of every image; images go into grid.z in chunks of at most 65 535.
+// Launches `kernel` over every tile of every image; images go into grid.z in chunks of at most 65 535, tile rows into
+// grid.y in chunks of at most 65 535 (GridParams::tile_row0), so any uint32 geometry the reference accepts runs.
 // max_log2_cols < 8 asks for squarer tiles (e.g. 4: 16 x 16 blocks, a wave = 16 x 4 blocks = 64 x 16 pixels):
 // worse coalescing, but the lanes of a wave see more homogeneous content, which is what wave-uniform shortcuts need.
 template <typename Kernel>
 hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream,
                         uint32_t max_log2_cols = 8) {
-  const uint32_t n_images = P.blocks_per_image ? P.total_blocks / P.blocks_per_image : 0;
-  if (n_images == 0) return hipSuccess;
+  if (P.n_images == 0 || P.block_rows == 0 || P.block_cols == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
   if (P.log2_tile_cols > max_log2_cols) P.log2_tile_cols = max_log2_cols;
+  // A lane addresses its block with a 32-bit offset from the tile's (64-bit, uniform) origin: up to 4 * 256 - 1 rows
+  // of stride in a 1 x 256 tile.  Rows of 4 MiB and more (or grids of 2^20 block columns and more, for the output
+  // offset) get 256 x 1 tiles, where the offset is at most three rows; rows of more than a third of 4 GiB take the
+  // 64-bit clamp-to-edge gather for every block.
+  if ((uint64_t)P.row_stride * 1024u >= (1ull << 32) || (uint64_t)P.block_cols * 4096u >= (1ull << 32)) P.log2_tile_cols = 8;
+  P.force_gather = (uint64_t)P.row_stride * 3u + 8192u >= (1ull << 32) ? 1u : 0u;
   const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
-  const uint32_t gx = (P.block_cols + cols - 1) / cols, gy = (P.block_rows + rows - 1) / rows;
-  if (gy > 65535u) return hipErrorInvalidValue;  // > 262 140 pixel rows
-  if ((uint64_t)P.row_stride * 1024u >= (1ull << 32) || (uint64_t)P.block_cols * 4096u >= (1ull << 32))
-    return hipErrorInvalidValue;                 // lane offsets inside a tile are 32-bit (rows of > 4 MiB)
-  for (uint32_t first = 0; first < n_images; first += 65535u) {
-    const uint32_t count = n_images - first < 65535u ? n_images - first : 65535u;
-    GridParams Q = P;
-    Q.src = P.src + (uint64_t)first * P.src_image_stride;
-    Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
-    hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(gx, gy, count),
-                       dim3(kThreadsPerWorkgroup), 0, stream, Q);
+  const uint32_t gx = (uint32_t)(((uint64_t)P.block_cols + cols - 1) / cols);
+  const uint32_t gy = (uint32_t)(((uint64_t)P.block_rows + rows - 1) / rows);
+  (void)hipGetLastError();  // do not attribute a stale error of another library on this thread to these launches
+  for (uint32_t first = 0; first < P.n_images; first += 65535u) {
+    const uint32_t count = P.n_images - first < 65535u ? P.n_images - first : 65535u;
+    for (uint32_t row0 = 0; row0 < gy; row0 += 65535u) {
+      GridParams Q = P;
+      Q.src = P.src + (uint64_t)first * P.src_image_stride;
+      Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
+      Q.tile_row0 = row0;
+      const uint32_t gyc = gy - row0 < 65535u ? gy - row0 : 65535u;
+      hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(gx, gyc, count),
+                         dim3(kThreadsPerWorkgroup), 0, stream, Q);
+    }
   }
   return hipGetLastError();
 }
@@ -61,6 +70,10 @@ struct PvrtcParams {
   uint32_t region_first = 0, region_blocks = 0;
 };
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream);
+// Scratch the PVRTC encoder needs between its two kernels for n_images size x size textures (8 bytes per block of one
+// launch group), and the thread-local caller-owned override of the library's internal scratch buffer.
+size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images);
+void pvrtc2_set_workspace(void *d_workspace, size_t bytes);
 
 struct DecodeParams {
   const uint8_t *blocks;

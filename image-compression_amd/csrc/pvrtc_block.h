@@ -3,8 +3,9 @@
 // Bit-exact with internal/pvrtc_compressor.cc (Morph :506-521, Modulate :527-540, Encode :551-580),
 // restructured so that a lane owns whole 8x4 blocks with their pixels in VGPRs:
 //  * GetExtremesFast (:255-329): the 5 fitness axes' "first minimum / first maximum" become unsigned
-//    min / max reductions over keys value*32 + idx  /  value*32 + (31-idx): lightness is a v_dot4_u32_u8 with
-//    32-bit keys, the R,B and G,A channels are two 13-bit keys per dword reduced with v_pk_min/max_u16;
+//    min / max reductions over keys value*256 + idx  /  value*256 + (31-idx), each key (pair) built by one v_perm_b32:
+//    lightness is a v_dot4_u32_u8 with 32-bit keys, the R,B and G,A channels are two 16-bit keys per dword reduced
+//    with v_pk_min/max_u16;
 //  * ColorDiff (:74-77), an L1 distance over 4 bytes, is one v_sad_u8;
 //  * ApplyColorChannelReduction (:337-349) is SWAR on the RGBA dword;
 //  * the bilinear up-sampling (:173-237) is separable and incremental on 16-bit channel pairs 0x00RR00BB /
@@ -121,19 +122,25 @@ struct Stash32 {
 // (an IMAGE index, pvrtc.cc:268-269) and only replaces it when a fitness value > 0 is seen.
 // Returns the two extreme colours, ordered so that colour A is not brighter than colour B.
 ICAMD_DEV void pvrtc_extremes(const uint32_t px[32], uint32_t image0, Stash32 &stash, uint32_t &col_a, uint32_t &col_b) {
-  // keys: value*32 + p (min side) and value*32 + (31-p) (max side).  The max-side key is the min-side key
-  // plus (31 - 2p): one full-rate add instead of recomputing it.  The lightness axis uses 32-bit keys; the R,B and
-  // G,A axes are packed two per dword (16-bit lanes, keys <= 255*32+31+31) and reduced with v_pk_min/max_u16.
+  // keys: value*256 + p (min side) and value*256 + (31-p) (max side): an unsigned min / max over them is the
+  // reference's "first pixel with the strictly smallest / largest value".  A key pair is ONE v_perm_b32: the channel
+  // byte of the pixel next to an index byte taken from a register that holds four consecutive indices.  The max-side
+  // key is the min-side key plus (31 - 2p): one full-rate add.  The lightness axis uses 32-bit keys (byte 1 of the
+  // 16-bit dot product is the reference's (77r + 150g + 28b) / 256); the R,B and G,A axes are two 16-bit keys per
+  // dword, reduced with v_pk_min/max_u16.
   uint32_t kmin_l = 0xffffffffu, kmax_l = 0u, kmin_rb = 0xffffffffu, kmax_rb = 0u, kmin_ga = 0xffffffffu, kmax_ga = 0u;
   ICAMD_UNROLL
   for (int p = 0; p < 32; p += 2) {
     uint32_t kl[2];
     ICAMD_UNROLL
     for (int q = 0; q < 2; ++q) {
-      const uint32_t c = px[p + q], pp = (uint32_t)(p + q) * 0x00010001u, up = (uint32_t)(31 - 2 * (p + q)) * 0x00010001u;
-      // lightness = (77r + 150g + 28b) / 256
-      kl[q] = ((udot4(c, 0x001c964du, 0u) >> 3) & ~31u) | (uint32_t)(p + q);
-      const uint32_t k_rb = ((c << 5) & 0x1fe01fe0u) | pp, k_ga = ((c >> 3) & 0x1fe01fe0u) | pp;
+      const uint32_t c = px[p + q], i = (uint32_t)((p + q) & 3);
+      const uint32_t idx4 = (uint32_t)((p + q) & ~3) * 0x01010101u + 0x03020100u;  // bytes: 4 consecutive indices
+      const uint32_t up = (uint32_t)(31 - 2 * (p + q)) * 0x00010001u;
+      // {hi, lo} = {c or dot, idx4}: selector bytes 0..3 pick an index byte, 4..7 a byte of the pixel
+      kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);              // [idx, lightness, 0, 0]
+      const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16);              // [idx, R, idx, B]
+      const uint32_t k_ga = perm(c, idx4, 0x07000500u | i | i << 16);              // [idx, G, idx, A]
       kmin_rb = pk_min_u16(kmin_rb, k_rb);
       kmin_ga = pk_min_u16(kmin_ga, k_ga);
       kmax_rb = pk_max_u16(kmax_rb, k_rb + up);
@@ -157,7 +164,7 @@ ICAMD_DEV void pvrtc_extremes(const uint32_t px[32], uint32_t image0, Stash32 &s
   for (int i = 0; i < 5; ++i) {
     const uint32_t lo = stash.get(kmin[i] & 31u);
     const uint32_t hi_block = stash.get(31u - (kmax[i] & 31u));
-    const uint32_t hi = (kmax[i] >> 5) == 0u ? image0 : hi_block;  // never-updated max -> image pixel 0
+    const uint32_t hi = (kmax[i] >> 8) == 0u ? image0 : hi_block;  // never-updated max -> image pixel 0
     const uint32_t d = sad_u8(lo, hi, 0u);
     const bool better = (i == 0) || d > best_diff;  // strict '>' scan from best_pair = 0 (pvrtc.cc:309-316)
     best_lo = better ? lo : best_lo;
@@ -253,17 +260,10 @@ ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t 
 //   pixel right of the row = x_in 0 of the next block: sources (centre, right), xw = 4
 // (a*c00 + b*c01 + c*c10 + d*c11 with a..d = (4-yw)(8-xw), (4-yw)xw, yw(8-xw), yw*xw is exactly
 //  (8-xw)*VL + xw*VR; the division by 32 is accumulate_mod's "take the high byte".)
+// V[c][v]: 8 * vertical blend of block column c (left, centre, right), v = a_rb, a_ga, b_rb, b_ga
 template <bool WITH_RIGHT>
-ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB bot[3], const uint32_t *pixels,
-                              uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
-  uint32_t V[3][4];
-  ICAMD_UNROLL
-  for (int c = 0; c < 3; ++c) {
-    V[c][0] = vblend_pair(yw, top[c].a_rb, bot[c].a_rb);
-    V[c][1] = vblend_pair(yw, top[c].a_ga, bot[c].a_ga);
-    V[c][2] = vblend_pair(yw, top[c].b_rb, bot[c].b_rb);
-    V[c][3] = vblend_pair(yw, top[c].b_ga, bot[c].b_ga);
-  }
+ICAMD_DEV void pvrtc_row_mods_v(const uint32_t V[3][4], const uint32_t *pixels, uint32_t right_pixel, uint32_t row[2],
+                                uint32_t *right_mod) {
   ICAMD_UNROLL
   for (int h = 0; h < 2; ++h) {
     uint32_t P[4], D[4];
@@ -293,6 +293,20 @@ ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB b
     for (int v = 0; v < 4; ++v) P[v] = (V[1][v] + V[2][v]) << 2;
     *right_mod = accumulate_mod(right_pixel, P, 1u, 0u);
   }
+}
+
+template <bool WITH_RIGHT>
+ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB bot[3], const uint32_t *pixels,
+                              uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
+  uint32_t V[3][4];
+  ICAMD_UNROLL
+  for (int c = 0; c < 3; ++c) {
+    V[c][0] = vblend_pair(yw, top[c].a_rb, bot[c].a_rb);
+    V[c][1] = vblend_pair(yw, top[c].a_ga, bot[c].a_ga);
+    V[c][2] = vblend_pair(yw, top[c].b_rb, bot[c].b_rb);
+    V[c][3] = vblend_pair(yw, top[c].b_ga, bot[c].b_ga);
+  }
+  pvrtc_row_mods_v<WITH_RIGHT>(V, pixels, right_pixel, row, right_mod);
 }
 
 ICAMD_DEV PvrtcAB pvrtc_expand(const PvrtcColors &c) {
@@ -489,62 +503,109 @@ ICAMD_DEV uint32_t pvrtc_acc_finish(const PvrtcBlockAcc &A, bool *mode_1bpp) {
 //                                strip), and the pixel right of it; toroidal wrap is the loader's business.
 // load_colours(j, c[3]):         reduced colours of block row j of the strip (j = -1 .. K), columns left/centre/right.
 // store(j, data, mode_1bpp, own): block j of the strip is finished; own = its reduced colours.
+//
+// The walk is organised by COLOUR-ROW PAIRS, not by blocks: rows 2, 3 of block s-1 and rows 0, 1 of block s all
+// interpolate between the colours of block rows s-1 (A) and s (B), with vertical weights 0, 1, 2, 3
+// (pvrtc.cc:216-227).  So the twelve vertical blends 8 ((4 - yw) A + yw B) of a pixel row are set up once per four
+// rows (32 A, and the step 8 (B - A)) and then just stepped -- twelve full-rate adds per row instead of re-expanding
+// six colours and re-blending them; two pixel-row buffers alternate, so no row is ever copied.
 template <typename PixelRowLoader, typename ColourRowLoader, typename BlockStore>
 ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, ColourRowLoader &load_colours,
                                   BlockStore &store) {
-  PvrtcColors top[3], mid[3], bot[3];
-  load_colours(-1, top);
-  load_colours(0, mid);
-  load_colours(1, bot);
-  uint32_t cur[8], cur_right = 0, nxt[8], nxt_right = 0, prev[2] = { 0, 0 };
+  PvrtcColors cc[3];
+  uint32_t A[3][4];  // colour row s-1 as channel pairs
+  load_colours(-1, cc);
   ICAMD_UNROLL
-  for (int i = 0; i < 8; ++i) nxt[i] = 0;
-  load_px(0u, cur, &cur_right);
+  for (int c = 0; c < 3; ++c) {
+    A[c][0] = pair_rb(cc[c].a); A[c][1] = pair_ga(cc[c].a); A[c][2] = pair_rb(cc[c].b); A[c][3] = pair_ga(cc[c].b);
+  }
+  load_colours(0, cc);
+  uint32_t buf0[8], buf1[8], right0 = 0, right1 = 0, prev[2] = { 0, 0 };
+  ICAMD_UNROLL
+  for (int i = 0; i < 8; ++i) buf1[i] = 0;
+  load_px(0u, buf0, &right0);
   PvrtcBlockAcc acc = { 0, 0, 0, 0, 0 };
-  PvrtcColors own = mid[1];
+  PvrtcColors own = cc[1];
   ICAMD_NOUNROLL
-  for (uint32_t j = 0;; ++j) {
-    // row 0 of block j -- for j == k_blocks the row below the strip, which only completes block K-1
-    if (j < k_blocks) load_px(4u * j + 1u, nxt, &nxt_right);
-    ICAMD_SCHED_FENCE();
+  for (uint32_t s = 0;; ++s) {
+    // colour rows (s-1, s): V = 32 A, dV = 8 (B - A).  Plain 32-bit arithmetic on the 16-bit channel pairs: every
+    // intermediate V is a true blend with both lanes in [0, 8160], so borrows between the lanes cancel exactly.
+    uint32_t V[3][4], dV[3][4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t b[4] = { pair_rb(cc[c].a), pair_ga(cc[c].a), pair_rb(cc[c].b), pair_ga(cc[c].b) };
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        V[c][v] = A[c][v] << 5;
+        dV[c][v] = (b[v] - A[c][v]) << 3;
+        A[c][v] = b[v];
+      }
+    }
+    const PvrtcColors own_next = cc[1];
+    if (s < k_blocks) load_colours((int)s + 1, cc);  // next segment's colours, in flight during these rows
     uint32_t row[2], right_mod = 0;
-    pvrtc_row_mods<true>(2u, top, mid, cur, cur_right, row, &right_mod);
-    if (j > 0) {  // "horizontal_count" = sum |m - m(x, y+1)| across the block boundary, then block j-1 is complete
+    if (s > 0) {
+      // rows 2 and 3 of block s-1: weights 0 and 1
+      load_px(4u * s - 1u, buf1, &right1);
+      ICAMD_SCHED_FENCE();
+      pvrtc_row_mods_v<true>(V, buf0, right0, row, &right_mod);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);  // "horizontal_count" = sum |m - m(x, y+1)| (pvrtc.cc:426-429)
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row(acc, 2, row, right_mod);
+      prev[0] = row[0]; prev[1] = row[1];
+      ICAMD_UNROLL
+      for (int c = 0; c < 3; ++c)
+        ICAMD_UNROLL
+        for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+      ICAMD_SCHED_FENCE();
+      load_px(4u * s, buf0, &right0);
+      ICAMD_SCHED_FENCE();
+      pvrtc_row_mods_v<true>(V, buf1, right1, row, &right_mod);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row(acc, 3, row, right_mod);
+      prev[0] = row[0]; prev[1] = row[1];
+      ICAMD_UNROLL
+      for (int c = 0; c < 3; ++c)
+        ICAMD_UNROLL
+        for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+      ICAMD_SCHED_FENCE();
+    } else {
+      ICAMD_UNROLL
+      for (int c = 0; c < 3; ++c)
+        ICAMD_UNROLL
+        for (int v = 0; v < 4; ++v) V[c][v] += 2u * dV[c][v];  // the strip starts at weight 2
+    }
+    // row 0 of block s, weight 2 -- for s == k_blocks the row below the strip, which only completes block K-1
+    if (s < k_blocks) load_px(4u * s + 1u, buf1, &right1);
+    ICAMD_SCHED_FENCE();
+    pvrtc_row_mods_v<true>(V, buf0, right0, row, &right_mod);
+    if (s > 0) {  // the vertical differences across the block boundary, then block s-1 is complete
       acc.hc = sad_u8(prev[0], row[0], acc.hc);
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
       bool one_bpp;
       const uint32_t data = pvrtc_acc_finish(acc, &one_bpp);
-      store(j - 1u, data, one_bpp, own);
+      store(s - 1u, data, one_bpp, own);
     }
-    if (j == k_blocks) break;
+    if (s == k_blocks) break;
+    own = own_next;
     acc.inter = acc.hc = acc.vc = acc.d1 = acc.d2 = 0;
     pvrtc_acc_row(acc, 0, row, right_mod);
-    prev[0] = row[0];
-    prev[1] = row[1];
+    prev[0] = row[0]; prev[1] = row[1];
     ICAMD_UNROLL
-    for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-    cur_right = nxt_right;
-    ICAMD_SCHED_FENCE();
-    ICAMD_UNROLL
-    for (int y = 1; y < 4; ++y) {
-      load_px(4u * j + (uint32_t)y + 1u, nxt, &nxt_right);
-      ICAMD_SCHED_FENCE();
-      if (y == 1) pvrtc_row_mods<true>(3u, top, mid, cur, cur_right, row, &right_mod);
-      else pvrtc_row_mods<true>((uint32_t)(y - 2), mid, bot, cur, cur_right, row, &right_mod);
-      acc.hc = sad_u8(prev[0], row[0], acc.hc);
-      acc.hc = sad_u8(prev[1], row[1], acc.hc);
-      pvrtc_acc_row(acc, y, row, right_mod);
-      prev[0] = row[0];
-      prev[1] = row[1];
+    for (int c = 0; c < 3; ++c)
       ICAMD_UNROLL
-      for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-      cur_right = nxt_right;
-      ICAMD_SCHED_FENCE();
-    }
-    own = mid[1];
-    ICAMD_UNROLL
-    for (int c = 0; c < 3; ++c) { top[c] = mid[c]; mid[c] = bot[c]; }
-    if (j + 1u < k_blocks) load_colours((int)j + 2, bot);
+      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_SCHED_FENCE();
+    // row 1 of block s, weight 3
+    load_px(4u * s + 2u, buf0, &right0);
+    ICAMD_SCHED_FENCE();
+    pvrtc_row_mods_v<true>(V, buf1, right1, row, &right_mod);
+    acc.hc = sad_u8(prev[0], row[0], acc.hc);
+    acc.hc = sad_u8(prev[1], row[1], acc.hc);
+    pvrtc_acc_row(acc, 1, row, right_mod);
+    prev[0] = row[0]; prev[1] = row[1];
+    ICAMD_SCHED_FENCE();
   }
 }
 

@@ -13,8 +13,10 @@
 //                               pixel right of each row, keeps a rolling 3x3 neighbourhood of reduced colours,
 //                               and computes every modulation value its mode decisions depend on itself
 //                               (pvrtc.cc:416-429 looks one pixel right / down): 36 + 1 per block instead of the
-//                               32 a block owns.  No LDS, no barrier, no inter-lane exchange: the reference's
-//                               1 B/px modulation image never exists.                       (Modulate + Encode)
+//                               32 a block owns.  No barrier, no inter-lane exchange of modulation values: the
+//                               reference's 1 B/px modulation image never exists.  The finished 8-byte blocks are
+//                               parked in a per-wave LDS tile laid out in Z order and written out as 512-byte
+//                               contiguous runs (16 B per lane) at the end of the strip.   (Modulate + Encode)
 //
 // A first fused version (one 320-lane workgroup per 16x16-block tile, A/B and modulation edges exchanged
 // through an LDS halo, two barriers) measured 1.0-1.25 ms per 16 x 4096^2 launch: with 50 KiB of LDS and a
@@ -45,6 +47,9 @@ __device__ __forceinline__ void load_block32(const uint32_t *p, uint32_t n, uint
 }
 
 // Per-thread grow-only device buffer.  Reuse from a different stream waits (on the device) for the previous user.
+// NOT usable under stream capture: a captured graph would bake in a pointer that a later, larger call frees, and
+// replays would bypass the event bookkeeping -- callers that capture provide their own workspace
+// (icamd_pvrtc2_set_workspace), one per graph.
 struct Workspace {
   int device = -1;
   void *ptr = nullptr;
@@ -52,11 +57,22 @@ struct Workspace {
   hipEvent_t done = nullptr;
   hipStream_t last_stream = nullptr;
   bool in_flight = false;
+  void *user_ptr = nullptr;  // caller-owned workspace (thread-local override); no allocation, no events
+  size_t user_bytes = 0;
   ~Workspace() {
     if (ptr) (void)hipFree(ptr);
     if (done) (void)hipEventDestroy(done);
   }
   hipError_t acquire(size_t bytes, hipStream_t stream, void **out) {
+    if (user_ptr) {
+      if (bytes > user_bytes) return hipErrorInvalidValue;
+      *out = user_ptr;
+      return hipSuccess;
+    }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return hipErrorStreamCaptureUnsupported;
+    (void)hipGetLastError();
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -80,12 +96,22 @@ struct Workspace {
     return hipSuccess;
   }
   hipError_t release(hipStream_t stream) {
+    if (user_ptr) return hipSuccess;
     last_stream = stream;
     in_flight = true;
     return hipEventRecord(done, stream);
   }
 };
 thread_local Workspace g_workspace;
+
+// images of one launch pair: as many as 4 GiB of pixels (and the 32-bit block index) allow
+uint64_t pvrtc_group(uint32_t size, uint32_t n_images) {
+  const uint64_t image_bytes = (uint64_t)size * size * 4u;
+  uint64_t group = image_bytes ? (4096ull << 20) / image_bytes : 1;
+  if (group < 1) group = 1;
+  if (group > n_images) group = n_images;
+  return group;
+}
 
 }  // namespace
 
@@ -102,6 +128,7 @@ struct PvrtcLaunch {
   // Encoded region of each image: the blocks whose Z-order index lies in [z_first, z_first + 2^log2_rblocks), a
   // rectangle of 2^log2_rw x 2^(log2_rblocks - log2_rw) blocks at (rx0, ry0).  Whole image: 0, 0, log2_bw, log2_bpi, 0.
   uint32_t rx0, ry0, log2_rw, log2_rblocks, z_first;
+  uint32_t stage_stores;    // encode kernel: park the strip's blocks in LDS and write them out in Z-order runs
 };
 
 // Morph: kMorphBlocksPerLane blocks per lane, software-pipelined with two pixel buffers -- the loads of the next
@@ -109,13 +136,15 @@ struct PvrtcLaunch {
 // does not drain during its ~700-instruction compute phases (5 waves/SIMD: the 32 KiB stash caps the occupancy).
 constexpr int kMorphBlocksPerLane = 4;
 
+// LDS of a morph workgroup: the per-lane pixel stash for index lookups, 8 planes x 256 lanes x 16 B = 32 KiB
+constexpr uint32_t kLdsDwords = 8 * kMorphLanes * 4;
+
 template <int kBlocksPerLane>
-__device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L) {
-  __shared__ uint32_t lds_stash[8][kMorphLanes][4];  // 32 KiB: per-lane pixel stash for index lookups
-  const uint32_t k0 = blockIdx.x * (kMorphLanes * kBlocksPerLane) + threadIdx.x;
+__device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds) {
+  const uint32_t k0 = wg * (kMorphLanes * kBlocksPerLane) + threadIdx.x;
   const uint32_t n = L.size, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
   Stash32 stash;
-  stash.base = &lds_stash[0][threadIdx.x][0];
+  stash.base = lds + threadIdx.x * 4u;  // [plane][lane][4 dwords]
   stash.row_dwords = kMorphLanes * 4;
   auto fetch = [&](uint32_t k, uint32_t px[32]) {
     const uint32_t image = k >> L.log2_bpi, b = k & bpi_mask;
@@ -150,11 +179,13 @@ __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L) {
 }
 
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
-  pvrtc2_morph<kMorphBlocksPerLane>(L);
+  __shared__ uint32_t lds[kLdsDwords];
+  pvrtc2_morph<kMorphBlocksPerLane>(L, blockIdx.x, lds);
 }
 // small launches (a few textures of <= 1024^2): one block per lane, four times as many workgroups
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_small_kernel(PvrtcLaunch L) {
-  pvrtc2_morph<1>(L);
+  __shared__ uint32_t lds[kLdsDwords];
+  pvrtc2_morph<1>(L, blockIdx.x, lds);
 }
 
 // Morph of a region plus its one-block ring (toroidal wrap), for encoding part of an image (one rank's share of a
@@ -180,38 +211,83 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rec
   L.ab[(by << L.log2_bw) + bx] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
 }
 
-extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
-  const uint32_t k = blockIdx.x * kEncodeLanes + threadIdx.x;
-  if (k >= L.total_strips) return;
-  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
-  const uint32_t log2_spi = L.log2_rblocks - L.log2_strip;  // log2(strips per image (region))
-  // consecutive lanes = consecutive block columns of one strip row: a wave reads 2 KiB contiguous per pixel row
-  const uint32_t image = k >> log2_spi, s = k & ((1u << log2_spi) - 1u);
-  const uint32_t bx = L.rx0 + (s & ((1u << L.log2_rw) - 1u)), by0 = L.ry0 + ((s >> L.log2_rw) << L.log2_strip);
-  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
-  const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
-  uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
-  const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
+// LDS tile of the staged stores: a wave's lanes are grouped in chunks of 2^sb consecutive block columns (sb =
+// log2_strip); a chunk's 2^sb x 2^sb blocks are 2^(2 sb) consecutive Z-order slots (x in the odd bits, y in the even
+// bits, pvrtc.cc:80-86) = one contiguous run of the output.  Chunk stride padded by two slots against bank conflicts.
+constexpr uint32_t kStageSlots = (kEncodeLanes / 8) * 66;  // sb = 3: 32 chunks x (64 + 2) slots of 8 bytes
 
-  auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
-    const uint32_t *q = img + (size_t)((by0 * 4u + r) & (n - 1u)) * n;
-    const uint4 v0 = *reinterpret_cast<const uint4 *>(q + bx * 8u), v1 = *reinterpret_cast<const uint4 *>(q + bx * 8u + 4);
-    pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
-    pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
-    *right_px = q[xr * 8u];
+__device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds) {
+  uint2 *lds_out = reinterpret_cast<uint2 *>(lds);
+  const uint32_t k = wg * kEncodeLanes + threadIdx.x;
+  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
+  const uint32_t sb = L.log2_strip;
+  const uint32_t log2_spi = L.log2_rblocks - sb;  // log2(strips per image (region))
+  // consecutive lanes = consecutive block columns of one strip row: a wave reads 2 KiB contiguous per pixel row
+  auto locate = [&](uint32_t kk, uint32_t &image, uint32_t &bx, uint32_t &by0) {
+    image = kk >> log2_spi;
+    const uint32_t s = kk & ((1u << log2_spi) - 1u);
+    bx = L.rx0 + (s & ((1u << L.log2_rw) - 1u));
+    by0 = L.ry0 + ((s >> L.log2_rw) << sb);
   };
-  auto load_colours = [&](int j, PvrtcColors c[3]) {
-    const uint2 *row = ab + (((by0 + (uint32_t)j) & bh_mask) << L.log2_bw);
-    const uint2 l = row[xl], m = row[bx], r = row[xr];
-    c[0].a = l.x; c[0].b = l.y;
-    c[1].a = m.x; c[1].b = m.y;
-    c[2].a = r.x; c[2].b = r.y;
-  };
-  const uint32_t zx = spread_bits16(bx) << 1;  // pvrtc.cc:80-86: x in the odd bits, y in the even bits
-  auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
-    dst[(zx | spread_bits16(by0 + j)) - L.z_first] = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
-  };
-  pvrtc_encode_strip(1u << L.log2_strip, load_px, load_colours, store);
+  const uint32_t chunk_slots = (1u << (2u * sb)) + 2u;
+  if (k < L.total_strips) {
+    uint32_t image, bx, by0;
+    locate(k, image, bx, by0);
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+    const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
+    uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
+    const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
+
+    auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
+      const uint32_t *q = img + (size_t)((by0 * 4u + r) & (n - 1u)) * n;
+      const uint4 v0 = *reinterpret_cast<const uint4 *>(q + bx * 8u), v1 = *reinterpret_cast<const uint4 *>(q + bx * 8u + 4);
+      pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
+      pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
+      *right_px = q[xr * 8u];
+    };
+    auto load_colours = [&](int j, PvrtcColors c[3]) {
+      const uint2 *row = ab + (((by0 + (uint32_t)j) & bh_mask) << L.log2_bw);
+      const uint2 l = row[xl], m = row[bx], r = row[xr];
+      c[0].a = l.x; c[0].b = l.y;
+      c[1].a = m.x; c[1].b = m.y;
+      c[2].a = r.x; c[2].b = r.y;
+    };
+    const uint32_t zx = spread_bits16(bx) << 1;  // pvrtc.cc:80-86: x in the odd bits, y in the even bits
+    // this lane's slots in the wave's LDS tile: chunk = lane >> sb, x inside the chunk = lane & (2^sb - 1)
+    const uint32_t sub = (1u << sb) - 1u;
+    uint2 *slot0 = lds_out + (threadIdx.x >> sb) * chunk_slots + (spread_bits16(threadIdx.x & sub) << 1);
+    auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
+      const uint2 v = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
+      if (L.stage_stores) slot0[spread_bits16(j)] = v;
+      else dst[(zx | spread_bits16(by0 + j)) - L.z_first] = v;
+    };
+    pvrtc_encode_strip(1u << sb, load_px, load_colours, store);
+  }
+  if (!L.stage_stores) return;
+  // Write-out: every lane stores 16 bytes (two Z-adjacent blocks) per round; 32 lanes cover one 512-byte run (sb = 3).
+  // Only lanes of this wave wrote the slots it reads (chunks never straddle a wave), and a wave's LDS operations
+  // complete in program order, so no barrier is needed.
+  const uint32_t wave_lane0 = threadIdx.x & ~63u, lane = threadIdx.x & 63u;
+  const uint32_t pairs_per_chunk = 1u << (2u * sb - 1u), log2_ppc = 2u * sb - 1u;
+  for (uint32_t t = 0; t < (1u << (sb - 1u)); ++t) {
+    const uint32_t pair = t * 64u + lane;                 // index among the wave's 2^(5 + sb) slot pairs
+    const uint32_t chunk = pair >> log2_ppc, within = (pair & (pairs_per_chunk - 1u)) << 1;
+    const uint32_t src_lane = wave_lane0 + (chunk << sb); // first lane of the chunk that produced these slots
+    const uint32_t kk = wg * kEncodeLanes + src_lane;
+    if (kk >= L.total_strips) continue;
+    uint32_t image, bx, by0;
+    locate(kk, image, bx, by0);
+    const uint2 *p = lds_out + (src_lane >> sb) * chunk_slots + within;
+    const uint2 a = p[0], b = p[1];
+    uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
+    const uint32_t z = ((spread_bits16(bx) << 1) | spread_bits16(by0)) - L.z_first + within;
+    store_stream16(dst + z, a.x, a.y, b.x, b.y);
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
+  __shared__ uint32_t lds[kStageSlots * 2];
+  pvrtc2_encode(L, blockIdx.x, lds);
 }
 
 const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_encode_kernel"; }
@@ -240,6 +316,7 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   uint2 *ab = nullptr;
   hipError_t e = g_workspace.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
   if (e != hipSuccess) return e;
+  (void)hipGetLastError();
   PvrtcLaunch L;
   L.src = P.src;
   L.dst = P.dst;
@@ -256,6 +333,7 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   L.z_first = P.region_first;
   L.log2_strip = log2_rh < 3 ? log2_rh : 3;
   while (L.log2_strip > 0 && (P.region_blocks >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
+  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip) ? 1u : 0u;
   L.total_blocks = 1u << log2_bpi;
   L.total_strips = P.region_blocks >> L.log2_strip;
   const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
@@ -272,14 +350,14 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   if (P.region_blocks != 0) return P.n_images == 1 ? launch_pvrtc2_region(P, stream) : hipErrorInvalidValue;
   const uint32_t bw = P.size / 8, bh = P.size / 4;
   const uint64_t bpi = (uint64_t)bw * bh;
-  // Images per launch pair.  Both kernels are bound by instruction issue rather than HBM, so re-reading the pixels
-  // from HBM in the encode kernel costs nothing, while every launch boundary costs a drain/fill of ~4 waves per
-  // SIMD: measured 0.67 / 0.60 / 0.58 / 0.57 ms per 16 x 4096^2 for groups of 64 MiB / 128 MiB / 512 MiB / 1 GiB
-  // of pixels (r01).  So: as many images per launch as the 32-bit block index and a 256 MiB workspace allow.
-  const uint64_t image_bytes = (uint64_t)P.size * P.size * 4u;
-  uint64_t group = image_bytes ? (4096ull << 20) / image_bytes : 1;
-  if (group < 1) group = 1;
-  if (group > P.n_images) group = P.n_images;
+  // Images per launch pair.  Every launch boundary costs a drain/fill of ~4 waves per SIMD: measured 0.67 / 0.60 /
+  // 0.58 / 0.57 ms per 16 x 4096^2 for groups of 64 MiB / 128 MiB / 512 MiB / 1 GiB of pixels (r01).  So: as many
+  // images per launch as the 32-bit block index and a 256 MiB workspace allow.  (r02: hosting the encode workgroups
+  // of one image group and the morph workgroups of the next in ONE grid, 1 : 2 interleaved -- the encode role is
+  // VALU-bound, the morph role memory-bound -- was measured at 0.55 / 0.59 / 0.68 ms for 2 / 4 / 8 stages against
+  // 0.53 ms for the two plain kernels: the shared 167-VGPR allocation and the extra fill/drain phases cost more than
+  // the overlap gains.  Removed.)
+  const uint64_t group = pvrtc_group(P.size, P.n_images);
   if (bpi * group >= (1ull << 31)) return hipErrorInvalidValue;
 
   // Workspace for the reduced colours (8 B per block of one image group).  A grow-only hipMalloc buffer per host
@@ -288,6 +366,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   uint2 *ab = nullptr;
   hipError_t e = g_workspace.acquire((size_t)(bpi * group * sizeof(uint2)), stream, reinterpret_cast<void **>(&ab));
   if (e != hipSuccess) return e;
+  (void)hipGetLastError();
   PvrtcLaunch L;
   L.ab = ab;
   L.src_image_stride = P.src_image_stride;
@@ -305,22 +384,41 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   L.rx0 = L.ry0 = L.z_first = 0;
   L.log2_rw = L.log2_bw;
   L.log2_rblocks = L.log2_bpi;
+  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip) ? 1u : 0u;
   for (uint64_t first = 0; first < P.n_images; first += group) {
     const uint64_t count = (P.n_images - first < group) ? P.n_images - first : group;
-    L.src = P.src + first * P.src_image_stride;
-    L.dst = P.dst + first * P.dst_image_stride;
-    L.total_blocks = (uint32_t)(bpi * count);
-    L.total_strips = L.total_blocks >> L.log2_strip;
-    const bool small = L.total_blocks < (uint32_t)kMorphBlocksPerLane * kFullChipLanes;
+    // images [i0, i0 + cnt) of this chunk as one launch descriptor
+    auto part = [&](uint64_t i0, uint64_t cnt, uint32_t log2_strip) {
+      PvrtcLaunch Q = L;
+      Q.src = P.src + (first + i0) * P.src_image_stride;
+      Q.dst = P.dst + (first + i0) * P.dst_image_stride;
+      Q.ab = ab + i0 * bpi;
+      Q.log2_strip = log2_strip;
+      Q.stage_stores = (log2_strip >= 1 && Q.log2_rw >= log2_strip) ? 1u : 0u;
+      Q.total_blocks = (uint32_t)(bpi * cnt);
+      Q.total_strips = Q.total_blocks >> log2_strip;
+      return Q;
+    };
+    const PvrtcLaunch Q = part(0, count, L.log2_strip);
+    const bool small = Q.total_blocks < (uint32_t)kMorphBlocksPerLane * kFullChipLanes;
     const uint32_t per_wg = kMorphLanes * (small ? 1 : kMorphBlocksPerLane);
-    const dim3 gm((L.total_blocks + per_wg - 1) / per_wg), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
-    if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, L);
-    else hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, L);
-    hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
+    const dim3 gm((Q.total_blocks + per_wg - 1) / per_wg), ge((Q.total_strips + kEncodeLanes - 1) / kEncodeLanes);
+    if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
+    else hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
+    hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, Q);
   }
   e = hipGetLastError();
   const hipError_t e2 = g_workspace.release(stream);
   return e != hipSuccess ? e : e2;
+}
+
+size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images) {
+  if (n_images == 0) return 0;
+  return (size_t)((uint64_t)(size / 8) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));
+}
+void pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
+  g_workspace.user_ptr = d_workspace;
+  g_workspace.user_bytes = d_workspace ? bytes : 0;
 }
 
 }  // namespace icamd

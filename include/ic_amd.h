@@ -85,6 +85,16 @@ int icamd_compress_and_pad(int compressor, int etc_strategy, int format,
 int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint32_t n_blocks, const void *d_src,
                                       void *d_dst_region, void *hip_stream);
 
+/* PVRTC scratch memory.  The PVRTC encoder keeps 8 bytes per block (the reference's two low-resolution colour images,
+ * pvrtc_compressor.cc:586-597) between its two kernels.  By default that lives in a per-thread, grow-only buffer the
+ * library allocates, which cannot be used while the stream is being CAPTURED into a HIP graph (the graph would keep a
+ * pointer that a later, larger call frees; a PVRTC call under capture then returns ICAMD_ERR_HIP).  To capture -- or to
+ * control the memory -- hand the library a buffer of at least icamd_pvrtc2_workspace_size(size, n_images) bytes for the
+ * calls that follow on THIS thread; the caller keeps it alive and exclusive for as long as work (or a graph) using it
+ * can run, one per graph.  NULL returns to the internal buffer. */
+size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images);
+int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes);
+
 /* ---- the hot path, device-resident (the roofline entry points) ----
  * Same contracts, but `d_buffer` / `d_out` are device pointers on the current HIP
  * device and the work is enqueued on `hip_stream` (a hipStream_t, NULL = default
@@ -109,7 +119,10 @@ int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
  *                    image dims for plain Compress.
  *   row_stride_bytes distance between source rows; *_image_stride_bytes between images.
  * Image i is read at d_src + i*src_image_stride_bytes and its blocks written at
- * d_dst + i*dst_image_stride_bytes (row-major blocks; PVRTC: Z-order, pvrtc.cc:551-580). */
+ * d_dst + i*dst_image_stride_bytes (row-major blocks; PVRTC: Z-order, pvrtc.cc:551-580).
+ * Any uint32 geometry runs (grids, batches and strides beyond one launch's limits are chunked internally).
+ * Alignment: DXT / ETC accept any pointers and strides; PVRTC reads 16 bytes at a time and requires d_src (and
+ * src_image_stride_bytes) 16-byte aligned, d_dst (and dst_image_stride_bytes) 8-byte aligned, else ICAMD_ERR_ARG. */
 int icamd_encode_device(int codec, int etc_strategy, int src_components, int swap_rb,
                         uint32_t height, uint32_t width, uint32_t grid_height, uint32_t grid_width,
                         uint32_t row_stride_bytes, uint32_t n_images,
@@ -134,7 +147,9 @@ int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width
 /* ---- "next" rows 8f.2-4: compressed-domain operations on one image's block grid ----
  * Compressor::Pad (compressor.h:104-106; helper.h:393-477; pad functors dxtc.cc:594-696, etc.cc:645-698) for the
  * case that really pads: the source grid covers (compressed_height, compressed_width) pixels, the result
- * (padded_height, padded_width); out_size must be the result's data size.  Returns ICAMD_FALSE for PVRTC and when a
+ * (padded_height, padded_width); out_size must be the result's data size.  Device pointers of the block-domain
+ * operations (pad, downsample: 4-byte; transcode: 8-byte) must be aligned, else ICAMD_ERR_ARG; the decoders accept
+ * any pointer.  Returns ICAMD_FALSE for PVRTC and when a
  * padded dimension has fewer blocks than the source (the reference either just duplicates the image, which the caller
  * does itself, or overruns its buffer). */
 int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,

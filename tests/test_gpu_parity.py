@@ -238,6 +238,25 @@ def test_pvrtc_batch_and_full_size_4096(pkg):
         assert a[z(bx, by)].tobytes() == b[z((bx + 16) % 32, (by + 16) % 64)].tobytes()
 
 
+def test_pvrtc_large_batches(pkg):
+    """Batches of large textures in one call (whole-batch morph launch, then whole-batch encode launch with the
+    LDS-staged Z-order stores), every texture against the oracle."""
+    import torch
+    for n, size in ((7, 4096), (5, 2048), (9, 1024)):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(size + n)
+        src = torch.randint(0, 256, (n, size, size, 4), dtype=torch.uint8, device="cuda", generator=g)
+        src[1::3, :, :, 3] = 255                       # opaque textures
+        src[2::3] = (src[2::3] >> 3) + 100             # low-contrast textures (1BPP blocks)
+        src[:, : size // 4, : size // 2] = src[:, :1, :1]  # flat area, colour of each texture's pixel 0
+        out = pkg.encode_device(T.PVRTC2, src, size, size, 4, n_images=n)
+        torch.cuda.synchronize()
+        host = src.cpu().numpy()
+        for i in range(n):
+            want = T.oracle_encode(T.PVRTC2, host[i], size, size, 4)
+            assert hashlib.sha256(out[i].cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(want).hexdigest(), (n, size, i)
+
+
 # ---- "next" row 8f.1: decoders
 
 def test_decoders_match_oracle_and_golden(pkg):
@@ -429,8 +448,9 @@ def test_concurrent_host_api_calls_from_several_threads(pkg):
 
 
 def test_device_entry_points_are_graph_capturable(pkg):
-    """The device entry points only enqueue kernels (and, for PVRTC, event records on a pre-grown workspace), so a
-    loop over many small textures can be captured once into a HIP graph and replayed (launch-bound regime)."""
+    """The device entry points only enqueue kernels, so a loop over many small textures can be captured once into a
+    HIP graph and replayed (launch-bound regime).  PVRTC needs scratch memory between its two kernels: under capture
+    the caller provides it (icamd_pvrtc2_set_workspace), one buffer per graph."""
     import torch
     n, size = 12, 64
     imgs = np.stack([T.s_mixed(size, size, 4, index=300 + i) for i in range(n)])
@@ -439,15 +459,222 @@ def test_device_entry_points_are_graph_capturable(pkg):
         per = pkg.encoded_size(codec, size, size)
         out = torch.zeros((n, per), dtype=torch.uint8, device="cuda")
         s = torch.cuda.Stream()
+        ws = torch.empty(pkg.pvrtc_workspace_size(size, 1), dtype=torch.uint8, device="cuda")
         with torch.cuda.stream(s):
-            pkg.encode_device(codec, src[0], size, size, 4, out=out[0:1], stream=s)  # warm-up (PVRTC workspace)
-            s.synchronize()
-            out.zero_()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
-                for i in range(n):
-                    pkg.encode_device(codec, src[i], size, size, 4, out=out[i:i + 1], stream=s)
+            if codec == T.PVRTC2:
+                pkg.pvrtc_set_workspace(ws)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    for i in range(n):
+                        pkg.encode_device(codec, src[i], size, size, 4, out=out[i:i + 1], stream=s)
+            finally:
+                pkg.pvrtc_set_workspace(None)
             g.replay()
             s.synchronize()
         for i in range(n):
             assert out[i].cpu().numpy().tobytes() == T.oracle_encode(codec, imgs[i], size, size, 4), (codec, i)
+
+
+def test_pvrtc_graphs_keep_their_own_workspace(pkg):
+    """Two PVRTC graphs of different sizes, each with its own caller-provided workspace, stay valid across later
+    (larger) eager calls on the same thread and can be replayed concurrently on different streams; without a
+    caller workspace a PVRTC call under capture is refused instead of baking the library's buffer into the graph."""
+    import torch
+    sizes = (64, 256)
+    imgs = [T.s_mixed(sz, sz, 4, index=700 + sz) for sz in sizes]
+    srcs = [_dev(im) for im in imgs]
+    outs = [torch.zeros((1, pkg.encoded_size(T.PVRTC2, sz, sz)), dtype=torch.uint8, device="cuda") for sz in sizes]
+    wss = [torch.empty(pkg.pvrtc_workspace_size(sz, 1), dtype=torch.uint8, device="cuda") for sz in sizes]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    graphs = []
+    for i, sz in enumerate(sizes):
+        with torch.cuda.stream(streams[i]):
+            pkg.pvrtc_set_workspace(wss[i])
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=streams[i]):
+                    pkg.encode_device(T.PVRTC2, srcs[i], sz, sz, 4, out=outs[i], stream=streams[i])
+            finally:
+                pkg.pvrtc_set_workspace(None)
+            graphs.append(g)
+    # an eager, larger call in between (grows / replaces the library's own scratch buffer)
+    big = T.s_noise(1024, 1024, 4, index=5)
+    assert _host(pkg.encode_device(T.PVRTC2, _dev(big), 1024, 1024, 4)) == T.oracle_encode(T.PVRTC2, big, 1024, 1024, 4)
+    for rep in range(3):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                graphs[i].replay()
+        torch.cuda.synchronize()
+        for i, sz in enumerate(sizes):
+            assert outs[i].cpu().numpy().tobytes() == T.oracle_encode(T.PVRTC2, imgs[i], sz, sz, 4), (rep, sz)
+    # too small a workspace is an argument error, not an overrun
+    pkg.pvrtc_set_workspace(wss[0])
+    try:
+        with pytest.raises(pkg.BackendError):
+            pkg.encode_device(T.PVRTC2, srcs[1], sizes[1], sizes[1], 4)
+    finally:
+        pkg.pvrtc_set_workspace(None)
+    torch.cuda.synchronize()
+
+
+# ---- BASELINE config 4 at its stated per-GPU size, and the N > 1 paths
+
+def test_config_c4_per_gpu_share_128_textures(pkg):
+    """Config 4 = 1024 textures of 1024^2, ETC1 kSmallerError, sharded over 8 GPUs by texture_range: rank 3's share
+    (textures 384..511) encoded by ONE launch, every texture hash-checked against the oracle."""
+    import os
+    import torch
+    from image_compression_amd import sharding
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    begin, end = sharding.texture_range(1024, 8, 3)
+    assert (begin, end) == (384, 512)
+    n, size = end - begin, 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x1234ABCD + 3)
+    src = torch.randint(0, 256, (n, size, size, 3), dtype=torch.uint8, device="cuda", generator=g)
+    # a quarter of the textures: mid-tones only (the unclamped shortcut fires), smooth ramps, flat saturated tiles
+    src[1::4] = (src[1::4] >> 2) + 96
+    ramp = (torch.arange(size, device="cuda").view(1, size, 1, 1) // 4).to(torch.uint8)
+    src[2::4] = (src[2::4] >> 5) + ramp
+    src[3::4] = (src[3::4, ::16, ::16] >> 7).mul(255).repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)
+    out = pkg.encode_device(T.ETC1, src, size, size, 3, etc_strategy=T.SMALLER_ERROR, n_images=n)
+    torch.cuda.synchronize()
+    host_src, host_out = src.cpu().numpy(), out.cpu().numpy()
+    for i in range(n):
+        want = T.oracle_encode(T.ETC1, host_src[i], size, size, 3, 0, T.SMALLER_ERROR, threads=cores)
+        assert hashlib.sha256(host_out[i].tobytes()).hexdigest() == hashlib.sha256(want).hexdigest(), begin + i
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    return json.loads(lines[-1])
+
+
+def test_bench_bare_command_self_launches_ranks(pkg):
+    """`python bench.py --gpus 2` outside torch.distributed.run starts its own two ranks and times both regions
+    (encode only; encode -> gather on rank 0, overlapped).  On a 1-GPU box the ranks share the GPU over gloo with the
+    gather staged through the host (debug backend); with >= 2 GPUs this is the real RCCL path."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    for extra in (["--workload", "dxt1_rgba8", "--size", "1024", "--batch", "3"], ["--config", "c4"]):
+        if extra == ["--config", "c4"] and backend == "gloo":
+            extra = ["--workload", "etc1_rgb888", "--size", "256", "--batch", "5"]
+        d = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", backend, "--no-cpu-baseline"] + extra)
+        assert d["n_gpus"] == 2 and d["steps"] == 4 and d["parity"].startswith("bit-exact")
+        assert d["value"] > 0 and d["value_with_gather"] > 0 and d["gather_ms"] > 0 and d["rank0_copy_matches"] is True
+        assert d["value_with_gather"] <= d["value"] * 1.05
+
+
+def test_bench_config_presets(pkg):
+    for cfg, codec, size in (("c3", "dxt5_rgba8", 8192), ("c5", "pvrtc2_rgba8", 4096)):
+        d = _run_bench(["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-api"])
+        assert d["config"]["codec"] == codec and d["config"]["texture"] == [size, size] and d["config"]["preset"] == cfg
+        assert d["parity"].startswith("bit-exact") and d["roofline"]["bound"] == "valu"
+
+
+def test_nccl_sharded_encode_and_gather_on_real_gpus(pkg):
+    """World size >= 2 over RCCL with the HIP encoder (skipped on a 1-GPU box): every rank encodes its texture_range
+    of a shared batch on its own GPU, gather_to_root assembles the output on rank 0, compared with the oracle."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs >= 2 GPUs (the pool's boxes have one)")
+    world = min(n_dev, 4)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", "29641",
+                        os.path.join(T.ROOT, "tests", "nccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+
+
+def test_single_process_batch_on_distinct_devices(pkg):
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs >= 2 GPUs (the pool's boxes have one)")
+    n, h, w = 11, 200, 264
+    imgs = [T.s_mixed(h, w, 3, index=i) for i in range(n)]
+    want = [T.oracle_compress(T.ETC, T.RGB, im, h, w) for im in imgs]
+    assert pkg.compress_batch_host(T.ETC, T.RGB, imgs, h, w, list(range(n_dev))) == want
+    assert pkg.compress_batch_host(T.ETC, T.RGB, imgs, h, w, [n_dev - 1, 0]) == want
+
+
+# ---- geometries beyond one launch's limits (chunked inside the library; the reference accepts any uint32 size)
+
+def test_more_than_65535_tile_rows(pkg):
+    """300 000 x 1024 px (wide grid: 256 x 1 tiles -> 75 000 tile rows, chunked over grid.y) and a 4-pixel-wide strip."""
+    import os
+    import torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    h, w = 300000, 1024
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    src = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    src[100000:200000] = (src[100000:200000] >> 3) + 90
+    got = _host(pkg.encode_device(T.DXT1, src, h, w, 3))
+    want = T.oracle_encode(T.DXT1, src.cpu().numpy(), h, w, 3, threads=cores)
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    dec = pkg.decode_device(T.DXT1, torch.frombuffer(bytearray(got), dtype=torch.uint8).cuda(), h, w)
+    want_px = T.oracle_decode(T.DXT1, want[: 8 * 256 * 64], 256, 1024)
+    assert _host(dec)[: 256 * 1024 * 3] == want_px.tobytes()
+    del src, dec
+    h, w = 300000, 8
+    img = T.s_noise(h, w, 4, index=8)
+    assert _host(pkg.encode_device(T.DXT5, _dev(img), h, w, 4)) == T.oracle_encode(T.DXT5, img, h, w, 4, threads=cores)
+
+
+def test_rows_longer_than_32_bit_lane_offsets(pkg):
+    """Row strides of 4 MiB and more (256 x 1 tiles) and of more than 4 GiB / 3 (the 64-bit gather path)."""
+    import torch
+    for stride, h, w in ((5 << 20, 64, 96), ((3 << 29) + 12, 9, 40)):
+        buf = torch.zeros(stride * (h - 1) + w * 3, dtype=torch.uint8, device="cuda")
+        img = T.s_mixed(h, w, 3, index=stride % 97)
+        rows = _dev(img.reshape(h, w * 3))
+        for y in range(h):
+            buf[y * stride: y * stride + w * 3] = rows[y]
+        for codec, strategy in ((T.DXT1, 2), (T.ETC1, 2), (T.ETC1, 3)):
+            out = pkg.encode_device(codec, buf, h, w, 3, etc_strategy=strategy, row_stride_bytes=stride,
+                                    src_image_stride_bytes=0)
+            assert _host(out) == T.oracle_encode(codec, img, h, w, 3, 0, strategy), (stride, codec)
+        del buf
+
+
+def test_batch_of_more_than_2_31_blocks(pkg):
+    """2 049 x 4096^2 DXT1 = 2^31 + 2^20 blocks in ONE call (16 GiB of output): every image reads the same source
+    (image stride 0), so every image's output must equal the first, and the first must equal the oracle."""
+    import os
+    import torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    n, size = 2049, 4096
+    img = T.s_smooth(size, size, 4, index=21)
+    img[:1024] = T.s_noise(1024, size, 4, index=21)
+    src = _dev(img)
+    per = pkg.encoded_size(T.DXT1, size, size)
+    out = torch.zeros((n, per), dtype=torch.uint8, device="cuda")
+    assert pkg.encode_device(T.DXT1, src, size, size, 4, n_images=n, src_image_stride_bytes=0, out=out) is not None
+    torch.cuda.synchronize()
+    assert out[0].cpu().numpy().tobytes() == T.oracle_encode(T.DXT1, img, size, size, 4, threads=cores)
+    first = out[0].view(torch.int64)
+    for i in range(1, n, 64):
+        assert bool((out[i:i + 64].view(torch.int64) == first).all()), i
+    # the decoder on the same scale: 2 049 images of blocks -> pixels of the last one
+    dec = pkg.decode_device(T.DXT1, out[n - 1].contiguous(), size, size)
+    assert _host(dec) == T.oracle_decode(T.DXT1, out[0].cpu().numpy().tobytes(), size, size).tobytes()
