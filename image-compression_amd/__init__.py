@@ -28,7 +28,7 @@ EXPORTS = [
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
     "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
-    "icamd_pvrtc2_set_workspace", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -87,6 +87,10 @@ def lib():
             L.icamd_pvrtc2_workspace_size.argtypes = [_u32, _u32]
             L.icamd_pvrtc2_set_workspace.restype = _ci
             L.icamd_pvrtc2_set_workspace.argtypes = [_vp, _sz]
+            L.icamd_host_register.restype = _ci
+            L.icamd_host_register.argtypes = [_vp, _sz]
+            L.icamd_host_unregister.restype = _ci
+            L.icamd_host_unregister.argtypes = [_vp]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -164,10 +168,20 @@ def compress_device(compressor, fmt, src, height, width, *, padding_bytes_per_ro
     return out[:n]
 
 
+def host_register(array):
+    """Page-locks a numpy array's memory (icamd_host_register); pair with host_unregister before it is freed."""
+    return _check(lib().icamd_host_register(ctypes.c_void_p(array.ctypes.data), array.nbytes), "icamd_host_register")
+
+
+def host_unregister(array):
+    return _check(lib().icamd_host_unregister(ctypes.c_void_p(array.ctypes.data)), "icamd_host_unregister")
+
+
 def compress_host(compressor, fmt, buffer, height, width, *, padding_bytes_per_row=0,
-                  etc_strategy=ETC_SMALLER_ERROR, padded=None, out_size=None):
+                  etc_strategy=ETC_SMALLER_ERROR, padded=None, out_size=None, out=None):
     """The host-buffer drop-in (H2D + kernel + D2H inside the library).  `buffer`: bytes-like / numpy uint8.
-    Returns bytes, or None where the reference returns false."""
+    Returns bytes, or None where the reference returns false.  `out`: a caller-owned numpy uint8 array of the exact
+    output size to write into (returned as is instead of bytes)."""
     import numpy as np
     src = np.ascontiguousarray(np.frombuffer(buffer, dtype=np.uint8) if not isinstance(buffer, np.ndarray) else buffer)
     if padded is None:
@@ -175,6 +189,15 @@ def compress_host(compressor, fmt, buffer, height, width, *, padding_bytes_per_r
     else:
         n = compute_compressed_data_size(compressor, fmt, max(height, padded[0]), max(width, padded[1])) \
             if out_size is None else out_size
+    if out is not None:
+        assert out.dtype == np.uint8 and out.size == n and out.flags["C_CONTIGUOUS"]
+        if padded is None:
+            st = lib().icamd_compress(compressor, etc_strategy, fmt, height, width, padding_bytes_per_row,
+                                      src.ctypes.data, out.ctypes.data, n)
+        else:
+            st = lib().icamd_compress_and_pad(compressor, etc_strategy, fmt, height, width, padded[0], padded[1],
+                                              padding_bytes_per_row, src.ctypes.data, out.ctypes.data, n)
+        return out if _check(st, "icamd_compress") else None
     out = np.zeros(max(n, 1), np.uint8)
     if padded is None:
         st = lib().icamd_compress(compressor, etc_strategy, fmt, height, width, padding_bytes_per_row,
@@ -189,7 +212,7 @@ def compress_host(compressor, fmt, buffer, height, width, *, padding_bytes_per_r
 
 def decode_device(codec, blocks, height, width, *, swap_rb=False, padding_bytes_per_row=0, n_images=1, stream=None):
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
-    comps = 4 if codec == DXT5 else 3
+    comps = 4 if codec in (DXT5, PVRTC2) else 3
     per_out = height * (width * comps + padding_bytes_per_row)
     per_in = encoded_size(codec, height, width)
     out = torch.zeros((n_images, per_out), dtype=torch.uint8, device=blocks.device)

@@ -68,6 +68,35 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_decode_kernel
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
   if (k < P.total_blocks) decode_one<ICAMD_ETC1>(P, k);
 }
+// PVRTC1 2bpp (extension, see decode_block.h): one 8x4 block per lane, lanes in raster order of the block grid (a
+// wave writes 64 x 32 B = 2 KiB contiguous per pixel row); the nine block words come from their Z-order slots.
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_kernel(DecodeParams P) {
+  const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+  if (k >= P.total_blocks) return;
+  const uint32_t img = fastdiv(k, P.div_bpi), rem = k - img * P.blocks_per_image;
+  const uint32_t by = fastdiv(rem, P.div_cols), bx = rem - by * P.block_cols;  // block_cols = width / 8
+  const U2 *blocks = reinterpret_cast<const U2 *>(P.blocks + (size_t)img * P.src_image_stride);
+  uint32_t mod[9], col[9];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const uint32_t nx = (bx + (uint32_t)dx) & (P.block_cols - 1u), ny = (by + (uint32_t)dy) & (P.block_rows - 1u);
+      const U2 w = blocks[spread_bits16(nx) << 1 | spread_bits16(ny)];
+      mod[3 * (dy + 1) + dx + 1] = w.x;
+      col[3 * (dy + 1) + dx + 1] = w.y;
+    }
+  uint32_t px[32];
+  decode_pvrtc2_block(mod, col, px);
+  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * P.row_stride + (size_t)bx * 32u;
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    U4 v0 = { px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3] };
+    U4 v1 = { px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7] };
+    *reinterpret_cast<U4 *>(dst + (size_t)y * P.row_stride) = v0;
+    *reinterpret_cast<U4 *>(dst + (size_t)y * P.row_stride + 16) = v1;
+  }
+}
 }  // extern "C"
 
 hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
@@ -77,6 +106,7 @@ hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_dxt1_decode_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_dxt5_decode_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_etc1_decode_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_PVRTC2) hipLaunchKernelGGL(icamd_pvrtc2_decode_kernel, grid, block, 0, stream, P);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

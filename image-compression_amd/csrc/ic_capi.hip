@@ -54,7 +54,7 @@ uint32_t ilog2(uint32_t x) {
 // Per-thread device staging for the host-buffer entry points (grow-only).
 struct Staging {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;  // two streams: bands of one image alternate between them
   void *d_in = nullptr, *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
   void *h_in = nullptr, *h_out = nullptr;  // pinned host mirrors (batch workers only)
@@ -66,9 +66,10 @@ struct Staging {
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
     if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) (void)hipStreamDestroy(stream2);
     d_in = d_out = h_in = h_out = nullptr;
     cap_in = cap_out = cap_hin = cap_hout = 0;
-    stream = nullptr;
+    stream = stream2 = nullptr;
   }
   int ensure(size_t in_bytes, size_t out_bytes, bool pinned = false) {
     int dev = 0;
@@ -78,6 +79,7 @@ struct Staging {
       device = dev;
     }
     if (!stream) ICAMD_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (!stream2) ICAMD_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking), "hipStreamCreate");
     if (in_bytes > cap_in) {
       if (d_in) (void)hipFree(d_in);
       d_in = nullptr; cap_in = 0;
@@ -302,6 +304,20 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
   return ICAMD_OK;
 }
 
+int icamd_host_register(void *host_ptr, size_t bytes) {
+  if (!host_ptr || bytes == 0) return fail(ICAMD_ERR_ARG, "icamd_host_register: null buffer");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  ICAMD_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault), "hipHostRegister");
+  return ICAMD_OK;
+}
+
+int icamd_host_unregister(void *host_ptr) {
+  if (!host_ptr) return fail(ICAMD_ERR_ARG, "icamd_host_unregister: null buffer");
+  ICAMD_HIP(hipHostUnregister(host_ptr), "hipHostUnregister");
+  return ICAMD_OK;
+}
+
 size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images) {
   if (!is_pow2(size) || size < 8) return 0;
   return icamd::pvrtc2_workspace_bytes(size, n_images);
@@ -353,39 +369,96 @@ int icamd_compress_device(int compressor, int etc_strategy, int format,
 // than the asynchronous DMA gains, so the batch path keeps the pageable copies.
 constexpr bool kBatchPinnedStaging = false;
 
-// `pinned`: stage through the Staging's page-locked mirrors (CPU memcpy + DMA that really is asynchronous), so that
-// several worker threads on one device overlap each other's copies and kernels; the single-call entry points copy
-// straight from / to the caller's pageable buffers instead (faster for one thread: 35 GB/s vs one memcpy's ~20).
+// Source bytes per band of the host-buffer pipeline (whole block rows): the kernel and the D2H copy of band i run
+// underneath the H2D copy of band i+1.  Measured on the MI355X box (r02, one 4096^2 kRGB image = 48 MiB, pageable
+// buffers, ms per call): bands of 2 / 4 / 8 / 16 / 24 / 32 MiB -> 2.33 / 1.91 / 1.38 / 1.32 / 1.21 / 1.09 (one band):
+// a PCIe copy needs tens of MiB to reach its ~50 GB/s, and there is little to hide (D2H + kernel = 15 % of the H2D
+// time), so bands are large and images below 64 MiB go in one piece.
+constexpr size_t kHostBandBytes = (size_t)32 << 20;
+
+// The host-buffer drop-in (Compressor::Compress / CompressAndPad, compressor.h:77-80,114-119): argument validation
+// first (nothing is staged or copied for a call the reference would refuse), then DXT / ETC images are cut into bands
+// of whole block rows -- blocks are independent and stored row-major (helper.h:202-214), so a band is an image of its
+// own and its blocks are one contiguous byte range of the output -- and band i's H2D copy, kernel and D2H copy are
+// enqueued on stream i % 2: the copy engines and the kernel of consecutive bands overlap.  Caller buffers that are
+// page-locked (icamd_host_register / hipHostMalloc) are DMA-ed directly at the PCIe rate; pageable ones go through the
+// runtime's own staging.  PVRTC (toroidal neighbourhood, Z-order output) is staged whole.
+// `pinned`: copy through the Staging's page-locked mirrors (batch workers only, see above).
 static int compress_host_common(Staging &st, bool pinned, bool and_pad, int compressor, int etc_strategy, int format,
                                 uint32_t height, uint32_t width, uint32_t padded_height, uint32_t padded_width,
                                 uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out,
                                 size_t out_size) {
   if (!buffer || !out || height == 0 || width == 0) return ICAMD_FALSE;
-  int comps = format_components(format);
-  if (compressor == ICAMD_COMPRESSOR_PVRTC) comps = 4;  // buffer is reinterpreted as RGBA8888, pvrtc.cc:664
-  if (comps == 0) return ICAMD_FALSE;
+  const bool pvrtc = compressor == ICAMD_COMPRESSOR_PVRTC;
+  int codec = ICAMD_PVRTC2, comps = 4;  // PVRTC: the buffer is reinterpreted as RGBA8888 whatever `format`, pvrtc.cc:664
+  bool swap = false;
+  uint32_t gh = height, gw = width;
+  if (pvrtc) {
+    if (and_pad) return ICAMD_FALSE;  // pvrtc.cc:684-691
+    // pvrtc.cc:636-667
+    if (!is_pow2(width) || !is_pow2(height) || width != height || padding_bytes_per_row != 0) return ICAMD_FALSE;
+    if (width % 8 != 0 || height % 4 != 0) return ICAMD_FALSE;
+    if (out_size != (size_t)(width * height / 4)) return ICAMD_FALSE;
+  } else {
+    if (!resolve_codec(compressor, format, &codec, &comps, &swap)) return ICAMD_FALSE;  // dxtc.cc:735-750, etc.cc:747-758
+    gh = std::max(height, padded_height);
+    gw = std::max(width, padded_width);
+    if (out_size != icamd_encoded_size(codec, gh, gw)) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
+  }
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  const size_t in_bytes = (size_t)height * ((size_t)width * comps + padding_bytes_per_row);
+  const size_t stride = (size_t)width * comps + padding_bytes_per_row;
+  if (stride > 0xffffffffull) return fail(ICAMD_ERR_ARG, "row stride does not fit 32 bits");
+  // the reference never touches the padding after the LAST row (pixel4x4.h:47-48 addresses row * stride + col)
+  const size_t in_bytes = (size_t)(height - 1) * stride + (size_t)width * comps;
   rc = st.ensure(in_bytes, std::max<size_t>(out_size, 1), pinned);
   if (rc != ICAMD_OK) return rc;
-  hipStream_t s = st.stream;
-  const void *h_src = buffer;
+  uint8_t *d_in = static_cast<uint8_t *>(st.d_in), *d_out = static_cast<uint8_t *>(st.d_out);
+  const uint8_t *h_src = buffer;
+  uint8_t *h_dst = out;
   if (pinned) {
     std::memcpy(st.h_in, buffer, in_bytes);
-    h_src = st.h_in;
+    h_src = static_cast<const uint8_t *>(st.h_in);
+    h_dst = static_cast<uint8_t *>(st.h_out);
   }
-  ICAMD_HIP(hipMemcpyAsync(st.d_in, h_src, in_bytes, hipMemcpyHostToDevice, s), "H2D copy");
-  rc = and_pad ? icamd_compress_and_pad_device(compressor, etc_strategy, format, height, width, padded_height,
-                                               padded_width, padding_bytes_per_row, st.d_in, st.d_out, out_size, s)
-               : icamd_compress_device(compressor, etc_strategy, format, height, width, padding_bytes_per_row,
-                                       st.d_in, st.d_out, out_size, s);
-  if (rc != ICAMD_OK) {
-    (void)hipStreamSynchronize(s);
-    return rc;
+  if (pvrtc) {
+    hipStream_t s = st.stream;
+    ICAMD_HIP(hipMemcpyAsync(d_in, h_src, in_bytes, hipMemcpyHostToDevice, s), "H2D copy");
+    rc = icamd_encode_device(ICAMD_PVRTC2, 0, 4, 0, height, width, height, width, width * 4u, 1, 0, 0, d_in, d_out, s);
+    if (rc != ICAMD_OK) {
+      (void)hipStreamSynchronize(s);
+      return rc;
+    }
+    ICAMD_HIP(hipMemcpyAsync(h_dst, d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
+    ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
+  } else {
+    const uint32_t block_bytes = codec == ICAMD_DXT5 ? 16u : 8u;
+    const uint32_t img_block_rows = num_blocks4(height), grid_block_rows = num_blocks4(gh), block_cols = num_blocks4(gw);
+    uint64_t band_rows = std::max<uint64_t>(1, kHostBandBytes / (4u * stride));  // block rows per band
+    if (band_rows * 2 > img_block_rows) band_rows = img_block_rows;               // small images: one band
+    int status = ICAMD_OK;
+    uint32_t band = 0;
+    for (uint64_t r0 = 0; r0 < img_block_rows && status == ICAMD_OK; r0 += band_rows, ++band) {
+      const bool last = r0 + band_rows >= img_block_rows;
+      const uint32_t rows_b = (uint32_t)(last ? img_block_rows - r0 : band_rows);        // block rows with pixels
+      const uint32_t h_b = (uint32_t)std::min<uint64_t>((uint64_t)rows_b * 4u, height - r0 * 4u);
+      const uint32_t grid_rows_b = last ? (uint32_t)(grid_block_rows - r0) : rows_b;     // + the pad rows below the image
+      const size_t src_off = (size_t)r0 * 4u * stride;
+      const size_t src_len = (size_t)(h_b - 1) * stride + (size_t)width * comps;
+      const size_t dst_off = (size_t)r0 * block_cols * block_bytes, dst_len = (size_t)grid_rows_b * block_cols * block_bytes;
+      hipStream_t s = (band & 1u) ? st.stream2 : st.stream;
+      hipError_t e = hipMemcpyAsync(d_in + src_off, h_src + src_off, src_len, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) { status = fail(ICAMD_ERR_HIP, "H2D copy", e); break; }
+      status = icamd_encode_device(codec, etc_strategy, comps, swap, h_b, width, grid_rows_b * 4u, gw, (uint32_t)stride, 1, 0,
+                                   0, d_in + src_off, d_out + dst_off, s);
+      if (status != ICAMD_OK) break;
+      e = hipMemcpyAsync(h_dst + dst_off, d_out + dst_off, dst_len, hipMemcpyDeviceToHost, s);
+      if (e != hipSuccess) status = fail(ICAMD_ERR_HIP, "D2H copy", e);
+    }
+    const hipError_t e1 = hipStreamSynchronize(st.stream), e2 = hipStreamSynchronize(st.stream2);
+    if (status != ICAMD_OK) return status;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(ICAMD_ERR_HIP, "stream synchronize", e1 != hipSuccess ? e1 : e2);
   }
-  ICAMD_HIP(hipMemcpyAsync(pinned ? st.h_out : out, st.d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
-  ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
   if (pinned) std::memcpy(out, st.h_out, out_size);
   return ICAMD_OK;
 }
@@ -415,7 +488,7 @@ static int decode_launch(int codec, int swap_rb, uint32_t height, uint32_t width
   P.height = height;
   P.width = width;
   P.block_rows = num_blocks4(height);
-  P.block_cols = num_blocks4(width);
+  P.block_cols = codec == ICAMD_PVRTC2 ? width / 8u : num_blocks4(width);  // PVRTC: 8x4-pixel blocks
   P.row_stride = row_stride;
   P.blocks_per_image = P.block_rows * P.block_cols;
   P.total_blocks = P.blocks_per_image * n_images;
@@ -430,13 +503,28 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
                         uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
                         const void *d_blocks, void *d_pixels, void *hip_stream) {
   if (!d_blocks || !d_pixels || height == 0 || width == 0) return ICAMD_FALSE;
-  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1) return ICAMD_FALSE;  // pvrtc.cc:669-672
+  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1 && codec != ICAMD_PVRTC2) return ICAMD_FALSE;
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const uint8_t *blocks = static_cast<const uint8_t *>(d_blocks);
   uint8_t *pixels = static_cast<uint8_t *>(d_pixels);
+  if (codec == ICAMD_PVRTC2) {
+    // EXTENSION (the reference's PvrtcCompressor::Decompress returns false, pvrtc.cc:669-672): the sizes
+    // PvrtcCompressor::Compress accepts (pvrtc.cc:636-650), RGBA8 out, no row padding, one launch per <= 2^30 blocks
+    if (!is_pow2(width) || width != height || width < 8 || padding_bytes_per_row != 0) return ICAMD_FALSE;
+    const uint64_t pv_bpi = (uint64_t)(width / 8) * (height / 4);
+    if (pv_bpi >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "PVRTC texture too large to decode");
+    const uint64_t per_launch = std::max<uint64_t>(1, ((1ull << 31) - 1) / pv_bpi);
+    for (uint64_t first = 0; first < n_images; first += per_launch) {
+      const uint32_t count = (uint32_t)std::min<uint64_t>(per_launch, n_images - first);
+      rc = decode_launch(codec, 0, height, width, width * 4u, count, src_image_stride_bytes, dst_image_stride_bytes,
+                         blocks + first * src_image_stride_bytes, pixels + first * dst_image_stride_bytes, stream);
+      if (rc != ICAMD_OK) return rc;
+    }
+    return ICAMD_OK;
+  }
   const uint32_t block_bytes = codec == ICAMD_DXT5 ? 16u : 8u;
   const uint32_t row_stride = width * (codec == ICAMD_DXT5 ? 4u : 3u) + padding_bytes_per_row;
   const uint64_t block_cols = num_blocks4(width), bpi = (uint64_t)num_blocks4(height) * block_cols;

@@ -63,10 +63,19 @@ size_t icamd_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width);
  * width*components + padding_bytes_per_row bytes of host memory; `out` is caller storage
  * of exactly out_size == icamd_compute_compressed_data_size(...) bytes (the reference's
  * external-storage contract, internal/compressor4x4_helper.cc:34-41).
- * Does H2D, kernel, D2H on an internal per-thread stream and returns when `out` is filled. */
+ * Returns when `out` is filled.  Inside: DXT / ETC images are cut into bands of whole block rows whose H2D copy,
+ * kernel and D2H copy are pipelined over two internal per-thread streams (bands are independent images: blocks are
+ * row-major, compressor4x4_helper.h:202-214); PVRTC is staged whole.  Pageable caller buffers work as they are;
+ * buffers page-locked with icamd_host_register (or hipHostMalloc) are DMA-ed at the PCIe rate. */
 int icamd_compress(int compressor, int etc_strategy, int format,
                    uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                    const uint8_t *buffer, uint8_t *out, size_t out_size);
+
+/* Optional: page-lock a caller buffer that will be passed to icamd_compress / icamd_compress_and_pad repeatedly
+ * (input images, output storage), so that the copies are true asynchronous DMA.  Thin wrappers over hipHostRegister /
+ * hipHostUnregister; the caller unregisters before freeing the memory. */
+int icamd_host_register(void *host_ptr, size_t bytes);
+int icamd_host_unregister(void *host_ptr);
 
 /* Compressor::CompressAndPad -- compressor.h:114-119; helper.h:479-520.
  * PVRTC returns ICAMD_FALSE like pvrtc_compressor.cc:684-691. */
@@ -131,7 +140,11 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
 
 /* ---- "next" row 8f.1: block decoders on device (Compressor::Decompress, compressor.h:85-86;
  * helper.h:218-262, dxtc.cc:167-267, etc.cc:198-289).  Writes height rows of
- * width*comps + padding_bytes_per_row bytes (comps = 4 for DXT5, else 3). */
+ * width*comps + padding_bytes_per_row bytes (comps = 4 for DXT5 and PVRTC2, else 3).
+ * codec ICAMD_PVRTC2 is an EXTENSION with PARITY UNPINNED: the reference has no PVRTC decoder
+ * (PvrtcCompressor::Decompress returns false, pvrtc_compressor.cc:669-672, and so does icamd_decompress); this one is
+ * written from the encoder's own rules (up-sampling pvrtc.cc:173-237, modulation :111-135, block layout :356-496,
+ * Z order :80-86) and needs square power-of-two sizes and padding_bytes_per_row == 0. */
 int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
                         uint32_t padding_bytes_per_row, uint32_t n_images,
                         size_t src_image_stride_bytes, size_t dst_image_stride_bytes,

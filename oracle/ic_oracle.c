@@ -710,9 +710,101 @@ static void decode_block(int codec, int swap, const uint8_t *blk, uint8_t px[16]
     }
 }
 
+/* ---- PVRTC1 2bpp decoder: EXTENSION, PARITY UNPINNED.  The reference has no PVRTC decoder
+ * (PvrtcCompressor::Decompress returns false, pvrtc.cc:669-672), so there is nothing to pin this against; it is
+ * written from the encoder's own rules so that decode(encode(x)) reproduces exactly what the encoder optimised for:
+ *   - block word layout and Z order: pvrtc.cc:551-580, :80-86;  colour fields: EncodeColors, pvrtc.cc:356-388,
+ *     expanded to 8 bits by bit replication exactly like ApplyBitDepthReduction (pvrtc.cc:93-106);
+ *   - A / B images up-sampled with GetInterpolatedColor2BPP / Interpolate4_2BPP (pvrtc.cc:173-237: centre of a block
+ *     = the stored colour, toroidal wrap, truncating / 32);
+ *   - modulation 0..3 = A, (5A+3B)/8, (3A+5B)/8, B (ApplyModulation, pvrtc.cc:120-144), i.e. weights 0, 3, 5, 8 of B;
+ *     1BPP blocks: one bit per pixel, 0 -> A, 1 -> B (CalculateBlockModulationData stores m / 2, pvrtc.cc:465-468);
+ *     2BPP blocks: 2 bits for the checkerboard pixels ((x ^ y) & 1 == 0) in raster order; the samples at bit 0
+ *     (pixel (0,0)) and bit 20 (pixel (4,2)) keep only their high bit (-> weight 0 or 8), their low bits select the
+ *     sub-mode (pvrtc.cc:474-487): bit 0 clear = average of the 4 orthogonal neighbours, else bit 20 set = average of
+ *     the vertical pair, clear = of the horizontal pair.  The encoder does not say how the skipped pixels are
+ *     reconstructed beyond the format comment (public/pvrtc_compressor.h:31-37); the PVRTC1 rule is used: the
+ *     neighbours' weights are averaged with rounding ((a+b+1)/2, (a+b+c+d+2)/4), neighbours wrap toroidally and may
+ *     belong to a block of the other kind.  Final colour = ((8 - w) A + w B) / 8 per channel, truncating. */
+static const int kPvWeight[4] = { 0, 3, 5, 8 };
+static rgba_t pvrtc_unpack_a(uint32_t c) {
+  rgba_t o;
+  if (c & (1u << 15)) {
+    o.r = (uint8_t)ext5((c >> 10) & 31); o.g = (uint8_t)ext5((c >> 5) & 31); o.b = (uint8_t)ext4((c >> 1) & 15); o.a = 255;
+  } else {
+    uint32_t b3 = (c >> 1) & 7, a3 = (c >> 12) & 7;
+    o.r = (uint8_t)ext4((c >> 8) & 15); o.g = (uint8_t)ext4((c >> 4) & 15);
+    o.b = (uint8_t)(b3 << 5 | b3 << 2 | b3 >> 1); o.a = (uint8_t)(a3 << 5 | a3 << 2 | a3 >> 1);
+  }
+  return o;
+}
+static rgba_t pvrtc_unpack_b(uint32_t c) {
+  rgba_t o;
+  if (c & (1u << 31)) {
+    o.r = (uint8_t)ext5((c >> 26) & 31); o.g = (uint8_t)ext5((c >> 21) & 31); o.b = (uint8_t)ext5((c >> 16) & 31); o.a = 255;
+  } else {
+    uint32_t a3 = (c >> 28) & 7;
+    o.r = (uint8_t)ext4((c >> 24) & 15); o.g = (uint8_t)ext4((c >> 20) & 15); o.b = (uint8_t)ext4((c >> 16) & 15);
+    o.a = (uint8_t)(a3 << 5 | a3 << 2 | a3 >> 1);
+  }
+  return o;
+}
+static uint32_t pvrtc_z_of(uint32_t bx, uint32_t by) { /* inverse of FromZOrder, pvrtc.cc:80-86 */
+  uint32_t z = 0;
+  for (int i = 0; i < 16; ++i) z |= ((by >> i) & 1u) << (2 * i) | ((bx >> i) & 1u) << (2 * i + 1);
+  return z;
+}
+/* explicit weight of pixel (x, y) of a block, or -1 where a 2BPP block stores nothing for it */
+static int pvrtc_stored_weight(uint32_t data, int two_bpp, uint32_t x, uint32_t y) {
+  if (!two_bpp) return ((data >> (8 * y + x)) & 1u) ? 8 : 0;
+  if ((x ^ y) & 1u) return -1;
+  uint32_t pos = 2 * (4 * y + (x >> 1)), s = (data >> pos) & 3u;
+  if (pos == 0 || pos == 20) return (s & 2u) ? 8 : 0;
+  return kPvWeight[s];
+}
+static int pvrtc_decode_image(const uint8_t *blocks, uint32_t n, uint8_t *out) {
+  uint32_t bw = n / 8, bh = n / 4, nblocks = bw * bh;
+  rgba_t *la = (rgba_t *)malloc(sizeof(rgba_t) * nblocks), *lb = (rgba_t *)malloc(sizeof(rgba_t) * nblocks);
+  uint32_t *data = (uint32_t *)malloc(sizeof(uint32_t) * nblocks);
+  uint8_t *two = (uint8_t *)malloc(nblocks);
+  if (!la || !lb || !data || !two) { free(la); free(lb); free(data); free(two); return 0; }
+  for (uint32_t by = 0; by < bh; ++by)
+    for (uint32_t bx = 0; bx < bw; ++bx) {
+      const uint8_t *p = blocks + 8 * (size_t)pvrtc_z_of(bx, by);
+      uint32_t d = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+      uint32_t c = (uint32_t)p[4] | (uint32_t)p[5] << 8 | (uint32_t)p[6] << 16 | (uint32_t)p[7] << 24;
+      data[by * bw + bx] = d; two[by * bw + bx] = (uint8_t)(c & 1u);
+      la[by * bw + bx] = pvrtc_unpack_a(c); lb[by * bw + bx] = pvrtc_unpack_b(c);
+    }
+#define PV_W(X, Y) pvrtc_stored_weight(data[(((Y) & (n - 1)) >> 2) * bw + (((X) & (n - 1)) >> 3)], \
+                                       two[(((Y) & (n - 1)) >> 2) * bw + (((X) & (n - 1)) >> 3)], (X) & 7u, (Y) & 3u)
+  for (uint32_t y = 0; y < n; ++y)
+    for (uint32_t x = 0; x < n; ++x) {
+      uint32_t blk = (y >> 2) * bw + (x >> 3);
+      int w = PV_W(x, y);
+      if (w < 0) {
+        int l = PV_W(x - 1, y), r = PV_W(x + 1, y), u = PV_W(x, y - 1), d = PV_W(x, y + 1);
+        if (!(data[blk] & 1u)) w = (l + r + u + d + 2) >> 2;
+        else if (data[blk] & (1u << 20)) w = (u + d + 1) >> 1;
+        else w = (l + r + 1) >> 1;
+      }
+      rgba_t a = pvrtc_interp(la, n, n, x, y), b = pvrtc_interp(lb, n, n, x, y);
+      uint8_t *o = out + 4 * ((size_t)y * n + x);
+      o[0] = (uint8_t)(((8 - w) * a.r + w * b.r) >> 3); o[1] = (uint8_t)(((8 - w) * a.g + w * b.g) >> 3);
+      o[2] = (uint8_t)(((8 - w) * a.b + w * b.b) >> 3); o[3] = (uint8_t)(((8 - w) * a.a + w * b.a) >> 3);
+    }
+#undef PV_W
+  free(la); free(lb); free(data); free(two);
+  return 1;
+}
+
 /* helper.h:218-262 */
 int ico_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const uint8_t *blocks, uint8_t *out) {
   if (!blocks || !out || h == 0 || w == 0) return 0;
+  if (codec == ICO_PVRTC2) { /* extension, see above; same size rules as PvrtcCompressor::Compress, pvrtc.cc:636-650 */
+    if (h != w || !is_pow2(w) || w < 8 || pad != 0) return 0;
+    return pvrtc_decode_image(blocks, w, out);
+  }
   if (codec != ICO_DXT1 && codec != ICO_DXT5 && codec != ICO_ETC1) return 0;
   int comps = codec == ICO_DXT5 ? 4 : 3;
   size_t bb = block_bytes(codec), stride = (size_t)w * (size_t)comps + pad;

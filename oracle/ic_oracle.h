@@ -65,7 +65,9 @@ size_t ico_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width);
 
 /* ---- decoders ("next" rows): DXT1/DXT5/ETC1 follow the reference
  * (dxtc.cc:167-267, etc.cc:198-289, helper.h:218-262).  out has
- * height * (width*comps + padding_bytes_per_row) bytes addressing, like the reference. */
+ * height * (width*comps + padding_bytes_per_row) bytes addressing, like the reference.
+ * ICO_PVRTC2: an EXTENSION with PARITY UNPINNED -- the reference has no PVRTC decoder (pvrtc.cc:669-672); written
+ * from the encoder's own interpolation / modulation rules (see ic_oracle.c); square power-of-two RGBA8 output. */
 int ico_decode(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                const uint8_t *blocks, uint8_t *out);
 

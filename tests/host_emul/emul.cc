@@ -45,7 +45,26 @@ extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_
   return 1;
 }
 
+static int emul_decode_pvrtc2(uint32_t n, const uint8_t *blocks, uint8_t *out) {
+  const uint32_t bw = n / 8, bh = n / 4;
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(blocks);
+  for (uint32_t by = 0; by < bh; ++by)
+    for (uint32_t bx = 0; bx < bw; ++bx) {
+      uint32_t mod[9], col[9], px[32];
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const uint32_t z = pvrtc_z_index((bx + bw + dx) % bw, (by + bh + dy) % bh);
+          mod[3 * (dy + 1) + dx + 1] = words[2 * z];
+          col[3 * (dy + 1) + dx + 1] = words[2 * z + 1];
+        }
+      decode_pvrtc2_block(mod, col, px);
+      for (int i = 0; i < 32; ++i) memcpy(out + 4 * ((size_t)(by * 4 + i / 8) * n + bx * 8 + i % 8), &px[i], 4);
+    }
+  return 1;
+}
+
 extern "C" int emul_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const uint8_t *blocks, uint8_t *out) {
+  if (codec == 3) return emul_decode_pvrtc2(w, blocks, out);
   const int comps = codec == 1 ? 4 : 3;
   const uint32_t rows = (h + 3) / 4, cols = (w + 3) / 4;
   const size_t stride = (size_t)w * comps + pad;

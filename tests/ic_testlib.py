@@ -125,7 +125,7 @@ def oracle_encode(codec, src, h, w, comps, swap=0, strategy=SMALLER_ERROR, gh=No
 
 
 def oracle_decode(codec, blocks, h, w, swap=0, pad=0):
-    comps = 4 if codec == DXT5 else 3
+    comps = 4 if codec in (DXT5, PVRTC2) else 3
     out = np.zeros(h * (w * comps + pad), np.uint8)
     b = np.frombuffer(blocks, np.uint8)
     ok = oracle().ico_decode(codec, swap, h, w, pad, _ptr(b), _ptr(out))

@@ -284,6 +284,35 @@ def test_decoders_match_oracle_and_golden(pkg):
             assert np.array_equal(got.cpu().numpy().reshape(-1), want), (codec, h, w, pad)
 
 
+def test_pvrtc_decoder_matches_oracle(pkg):
+    """PVRTC 2bpp decoder on the device (extension, parity unpinned: the reference has no PVRTC decoder) against the
+    oracle's statement of the same rules: encoder output, random block words, a batch, and the 4096^2 size."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(31))
+    for n in (8, 16, 32, 128, 512):
+        cases = [T.oracle_encode(T.PVRTC2, T.GENERATORS[gen](n, n, 4, index=n + 1), n, n, 4) for gen in ("noise", "mixed", "flat")]
+        cases.append(rng.integers(0, 256, size=n * n // 4, dtype=np.uint8).tobytes())
+        for blocks in cases:
+            dec = pkg.decode_device(T.PVRTC2, _dev(np.frombuffer(blocks, np.uint8)), n, n)
+            assert _host(dec) == T.oracle_decode(T.PVRTC2, blocks, n, n).tobytes(), n
+    n, k = 64, 5
+    words = rng.integers(0, 256, size=(k, n * n // 4), dtype=np.uint8)
+    dec = pkg.decode_device(T.PVRTC2, _dev(words), n, n, n_images=k)
+    torch.cuda.synchronize()
+    for i in range(k):
+        assert dec[i].cpu().numpy().tobytes() == T.oracle_decode(T.PVRTC2, words[i].tobytes(), n, n).tobytes()
+    n = 4096
+    img = T.s_smooth(n, n, 4, index=12)
+    enc = pkg.encode_device(T.PVRTC2, _dev(img), n, n, 4)
+    dec = pkg.decode_device(T.PVRTC2, enc.reshape(-1), n, n)
+    want = T.oracle_decode(T.PVRTC2, _host(enc), n, n)
+    assert hashlib.sha256(_host(dec)).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    # refusals: not square / not a power of two / row padding; the host-buffer Decompress stays `false` like the reference
+    assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 4096, 2048) is None
+    assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 24, 24) is None
+    assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 64, 64, padding_bytes_per_row=4) is None
+
+
 def test_pvrtc_call_sequences_host_api(pkg):
     # Regression: results must not depend on what ran before in the process (workspace / staging reuse).
     # A 128^2 image spans two workgroups of each PVRTC kernel, 64^2 and 8^2 only one.
@@ -678,3 +707,39 @@ def test_batch_of_more_than_2_31_blocks(pkg):
     # the decoder on the same scale: 2 049 images of blocks -> pixels of the last one
     dec = pkg.decode_device(T.DXT1, out[n - 1].contiguous(), size, size)
     assert _host(dec) == T.oracle_decode(T.DXT1, out[0].cpu().numpy().tobytes(), size, size).tobytes()
+
+
+def test_host_api_band_pipeline(pkg):
+    """icamd_compress / icamd_compress_and_pad on images large enough for several bands (bands of whole block rows,
+    two streams): ragged heights, row padding, pad grids below / right of the image, page-locked caller buffers."""
+    import os
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    for compressor, fmt, codec, h, w, pad, padded in (
+            (T.DXTC, T.RGB, T.DXT1, 4096, 4096, 0, None), (T.DXTC, T.BGRA, T.DXT5, 2051, 3000, 7, None),
+            (T.ETC, T.RGB, T.ETC1, 2999, 2048, 3, None), (T.DXTC, T.BGR, T.DXT1, 3001, 2500, 5, (3100, 2600)),
+            (T.DXTC, T.RGBA, T.DXT5, 1500, 4000, 0, (1500, 4100)), (T.ETC, T.RGB, T.ETC1, 2100, 1900, 0, (2133, 1900))):
+        comps = T.comps_of(fmt)
+        img = T.s_smooth(h, w, comps, index=h % 13)
+        img[: h // 3] = T.s_noise(h // 3, w, comps, index=w % 11)
+        src = T.with_row_padding(img, pad)[: (h - 1) * (w * comps + pad) + w * comps]  # no padding after the LAST row
+        if padded is None:
+            want = T.oracle_encode(codec, src, h, w, comps, int(fmt in (T.BGR, T.BGRA)), stride=w * comps + pad, threads=cores)
+        else:
+            want = T.oracle_encode(codec, src, h, w, comps, int(fmt in (T.BGR, T.BGRA)), gh=padded[0], gw=padded[1],
+                                   stride=w * comps + pad, threads=cores)
+        got = pkg.compress_host(compressor, fmt, src, h, w, padding_bytes_per_row=pad, padded=padded)
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), (compressor, fmt, h, w, pad, padded)
+    # page-locked caller buffers (icamd_host_register): same bytes
+    h = w = 2048
+    img = np.ascontiguousarray(T.s_mixed(h, w, 3, index=2))
+    out = np.zeros(pkg.compute_compressed_data_size(T.DXTC, T.RGB, h, w), np.uint8)
+    pkg.host_register(img)
+    pkg.host_register(out)
+    try:
+        assert pkg.compress_host(T.DXTC, T.RGB, img, h, w, out=out) is out
+        assert out.tobytes() == T.oracle_encode(T.DXT1, img, h, w, 3, threads=cores)
+    finally:
+        pkg.host_unregister(out)
+        pkg.host_unregister(img)
+    # a wrong out_size is refused before anything is staged (and a huge one allocates nothing)
+    assert pkg.compress_host(T.DXTC, T.RGB, img, h, w, out_size=8) is None

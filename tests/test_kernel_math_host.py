@@ -215,3 +215,75 @@ def test_dxt5_alpha_index_search_exhaustive(emul):
             g_ = np.frombuffer(got, np.uint8).reshape(m, 16)[:, :8]
             bad = np.nonzero((w_ != g_).any(axis=1))[0][:5]
             raise AssertionError([(a[i].tolist(), w_[i].tolist(), g_[i].tolist()) for i in bad])
+
+
+def _pvrtc_random_words(g, n_blocks):
+    """Random PVRTC block words (any bit pattern decodes; both block kinds and all sub-modes occur)."""
+    return g.integers(0, 256, size=8 * n_blocks, dtype=np.uint8)
+
+
+def test_pvrtc_decode_math_matches_oracle(emul):
+    """PVRTC 2bpp decoder (extension, parity unpinned -- the reference has none): device block math vs the oracle's
+    plain-C statement of the same rules, on encoder output and on random block words."""
+    emul.emul_decode.restype = ctypes.c_int
+    emul.emul_decode.argtypes = [T.ci, T.ci, T.u32, T.u32, T.u32, T.vp, T.vp]
+    g = np.random.Generator(np.random.PCG64(23))
+    for n in (8, 16, 64, 128):
+        cases = [np.frombuffer(T.oracle_encode(T.PVRTC2, T.GENERATORS[gen](n, n, 4, index=n), n, n, 4), np.uint8)
+                 for gen in ("noise", "smooth", "flat", "mixed")]
+        cases.append(_pvrtc_random_words(g, n * n // 32))
+        for blocks in cases:
+            want = T.oracle_decode(T.PVRTC2, blocks.tobytes(), n, n)
+            out = np.zeros(n * n * 4, np.uint8)
+            b = np.ascontiguousarray(blocks)
+            assert emul.emul_decode(T.PVRTC2, 0, n, n, 0, b.ctypes.data, out.ctypes.data)
+            assert np.array_equal(out, want), n
+
+
+def test_pvrtc_decode_properties():
+    """What ties the (reference-less) PVRTC decoder to the ENCODER's model: a solid texture decodes to the encoder's
+    channel-reduced colour (pvrtc.cc:337-349); in a 1BPP block the block-centre pixels (x % 8 == 4, y % 4 == 2), where
+    the up-sampling is the identity (pvrtc.cc:216-227), are exactly the stored colour A or B; and decoding a smooth
+    opaque texture gives a sane PSNR."""
+    for colour, want in (((200, 100, 50, 255), {(206, 99, 50, 255), (206, 99, 51, 255)}),   # R5 G5 B4 / B5
+                         ((200, 100, 50, 100), {(204, 102, 36, 109), (204, 102, 51, 109)})):  # R4 G4 B3 / B4, A3
+        img = np.zeros((32, 32, 4), np.uint8)
+        img[...] = colour
+        dec = T.oracle_decode(T.PVRTC2, T.oracle_encode(T.PVRTC2, img, 32, 32, 4), 32, 32).reshape(-1, 4)
+        assert set(map(tuple, dec.tolist())) <= want, set(map(tuple, dec.tolist()))
+
+    def rep(v, bits):
+        e = v << (8 - bits)
+        return e | e >> bits | (e >> 2 * bits if bits <= 3 else 0)
+    n = 64
+    img = T.s_flat(n, n, 4, index=4)
+    blocks = np.frombuffer(T.oracle_encode(T.PVRTC2, img, n, n, 4), np.uint8).reshape(-1, 8)
+    dec = T.oracle_decode(T.PVRTC2, blocks.tobytes(), n, n).reshape(n, n, 4)
+    checked = 0
+    for by in range(n // 4):
+        for bx in range(n // 8):
+            z = 0
+            for i in range(16):
+                z |= ((by >> i) & 1) << (2 * i) | ((bx >> i) & 1) << (2 * i + 1)
+            data = int.from_bytes(blocks[z, :4].tobytes(), "little")
+            cw = int.from_bytes(blocks[z, 4:].tobytes(), "little")
+            if cw & 1:
+                continue  # 2BPP block
+            if (data >> (8 * 2 + 4)) & 1:  # pixel (4, 2) uses colour B
+                c = (rep(cw >> 26 & 31, 5), rep(cw >> 21 & 31, 5), rep(cw >> 16 & 31, 5), 255) if cw >> 31 else \
+                    (rep(cw >> 24 & 15, 4), rep(cw >> 20 & 15, 4), rep(cw >> 16 & 15, 4), rep(cw >> 28 & 7, 3))
+            else:
+                c = (rep(cw >> 10 & 31, 5), rep(cw >> 5 & 31, 5), rep(cw >> 1 & 15, 4), 255) if cw >> 15 & 1 else \
+                    (rep(cw >> 8 & 15, 4), rep(cw >> 4 & 15, 4), rep(cw >> 1 & 7, 3), rep(cw >> 12 & 7, 3))
+            assert tuple(dec[by * 4 + 2, bx * 8 + 4].tolist()) == c, (bx, by)
+            checked += 1
+    assert checked > 20
+    y, x = np.mgrid[0:256, 0:256]
+    img = np.zeros((256, 256, 4), np.uint8)
+    img[..., 0] = (128 + 100 * np.sin(x / 40.0)).astype(np.uint8)
+    img[..., 1] = (128 + 100 * np.cos(y / 33.0)).astype(np.uint8)
+    img[..., 2] = ((x + y) // 2).astype(np.uint8)
+    img[..., 3] = 255
+    dec = T.oracle_decode(T.PVRTC2, T.oracle_encode(T.PVRTC2, img, 256, 256, 4), 256, 256).reshape(256, 256, 4)
+    mse = ((dec.astype(np.float64) - img) ** 2).mean()
+    assert 10 * np.log10(255 * 255 / mse) > 30.0
