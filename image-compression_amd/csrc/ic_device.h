@@ -219,10 +219,12 @@ struct TileCoord {
 };
 // WIDE = the tile is 256 x 1 blocks (block grids more than 128 columns wide): the lane's row IS the tile's row, so every
 // row-dependent quantity is workgroup-uniform as well.
-template <bool WIDE>
+// WIDE_ROWS > 1: the workgroup covers WIDE_ROWS block rows and every lane encodes WIDE_ROWS vertically adjacent blocks
+// (the returned coordinate is the first one; the caller steps brow0 / brow).
+template <bool WIDE, uint32_t WIDE_ROWS = 1>
 __device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
   TileCoord t;
-  const uint32_t cols = WIDE ? 256u : 1u << P.log2_tile_cols, rows = WIDE ? 1u : 256u >> P.log2_tile_cols;
+  const uint32_t cols = WIDE ? 256u : 1u << P.log2_tile_cols, rows = WIDE ? WIDE_ROWS : 256u >> P.log2_tile_cols;
   t.lx = WIDE ? threadIdx.x : threadIdx.x & (cols - 1u);
   t.ly = WIDE ? 0u : threadIdx.x >> P.log2_tile_cols;
   t.bcol0 = blockIdx.x * cols;

@@ -24,7 +24,7 @@ inline uint32_t tile_log2_cols(uint32_t block_cols) {
 // worse coalescing, but the lanes of a wave see more homogeneous content, which is what wave-uniform shortcuts need.
 template <typename Kernel>
 hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream,
-                        uint32_t max_log2_cols = 8) {
+                        uint32_t max_log2_cols = 8, uint32_t wide_rows = 1) {
   if (P.n_images == 0 || P.block_rows == 0 || P.block_cols == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
   if (P.log2_tile_cols > max_log2_cols) P.log2_tile_cols = max_log2_cols;
@@ -34,7 +34,7 @@ hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, 
   // 64-bit clamp-to-edge gather for every block.
   if ((uint64_t)P.row_stride * 1024u >= (1ull << 32) || (uint64_t)P.block_cols * 4096u >= (1ull << 32)) P.log2_tile_cols = 8;
   P.force_gather = (uint64_t)P.row_stride * 3u + 8192u >= (1ull << 32) ? 1u : 0u;
-  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
+  const uint32_t cols = 1u << P.log2_tile_cols, rows = P.log2_tile_cols == 8 ? wide_rows : 256u >> P.log2_tile_cols;
   const uint32_t gx = (uint32_t)(((uint64_t)P.block_cols + cols - 1) / cols);
   const uint32_t gy = (uint32_t)(((uint64_t)P.block_rows + rows - 1) / rows);
   (void)hipGetLastError();  // do not attribute a stale error of another library on this thread to these launches
