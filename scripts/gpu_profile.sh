@@ -1,21 +1,34 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats for every bench workload, plus separate
-# PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950) for the HBM traffic of each kernel.
-# Output: gpurun_out/prof/<workload>/..., summarised by scripts/summarize_profiles.py into profiles/.
+# PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950) for the HBM traffic of each kernel, plus
+# SQ-only passes for the other contents / ETC1 strategies (executed VALU instructions per workload/content/strategy).
+# Output: gpurun_out/prof/<tag>/..., summarised by scripts/summarize_profiles.py into profiles/.
 # Usage: scripts/gpu_profile.sh [workload ...]
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
-mkdir -p "$O"
+rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 WLS=${@:-dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8}
+SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 for wl in $WLS; do
-  B="python bench.py --steps 20 --warmup 3 --workload $wl --no-cpu-baseline --no-verify"
+  B="python bench.py --steps 20 --warmup 3 --workload $wl --no-cpu-baseline --no-verify --no-host-api"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$wl/trace" -o "$wl" -- $B > "$O/$wl.trace.log" 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/$wl/pmc_fetch" -o "$wl" -- $B > "$O/$wl.fetch.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/$wl/pmc_write" -o "$wl" -- $B > "$O/$wl.write.log" 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$O/$wl/pmc_sq" -o "$wl" -- $B > "$O/$wl.sq.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/$wl/pmc_sq" -o "$wl" -- $B > "$O/$wl.sq.log" 2>&1
   grep -h '^{' "$O/$wl.trace.log" | tail -1 > "$O/$wl.bench.json"
+  for c in smooth flat; do
+    tag=${wl}__${c}__s2
+    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$O/$tag/pmc_sq" -o "$tag" -- $B --content $c > "$O/$tag.sq.log" 2>&1
+  done
 done
-find "$O" -name '*.csv' | head -40
+case " $WLS " in *" etc1_rgb888 "*)
+  for s in 0 1 3; do
+    tag=etc1_rgb888__noise__s$s
+    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$O/$tag/pmc_sq" -o "$tag" -- \
+      python bench.py --steps 20 --warmup 3 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline --no-verify --no-host-api > "$O/$tag.sq.log" 2>&1
+  done;;
+esac
+find "$O" -name '*.csv' | wc -l

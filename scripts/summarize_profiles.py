@@ -28,7 +28,7 @@ def counters(path):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     os.makedirs(DST, exist_ok=True)
     tpath = os.path.join(DST, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -49,7 +49,7 @@ def main():
                 w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
         summary = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 "
-                   "--workload %s --no-cpu-baseline --no-verify" % wl, "kernels": {}}
+                   "--workload %s --no-cpu-baseline --no-verify --no-host-api" % wl, "kernels": {}}
         for r in rows:
             if r["Name"].startswith("icamd_"):
                 summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
@@ -82,6 +82,32 @@ def main():
         traffic[wl] = int(b)
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
+    # executed VALU instructions per workload / content / ETC strategy: what bench.py's roofline.valu_frac is built on
+    # (it only reports the fraction when the key of the run matches a profile taken with exactly that configuration)
+    vpath = os.path.join(DST, "valu_insts.json")
+    valu = json.load(open(vpath)) if os.path.exists(vpath) else {}
+    mpix = 16 * 4096 * 4096 / 1e6  # pixels of one bench step
+    for tag in sorted(os.listdir(SRC)):
+        d = os.path.join(SRC, tag)
+        if not os.path.isdir(d):
+            continue
+        wl, content, strat = (tag.split("__") + ["noise", "s2"])[:3] if "__" in tag else (tag, "noise", "s2")
+        sq = counters(os.path.join(d, "pmc_sq", tag + "_counter_collection.csv"))
+        insts = sum(v for (k, c), v in sq.items() if c == "SQ_INSTS_VALU")
+        if insts <= 0:
+            continue
+        calls_per_step = 1.0
+        if wl.startswith("pvrtc"):
+            pass  # morph + encode: one launch each per step, summed
+        key = "%s/%s/%s" % (wl, content, strat if wl.startswith("etc1") else "s0")
+        lanes_per_block = 32.0 if wl.startswith("pvrtc") else 16.0  # pixels per block
+        valu[key] = {"valu_wave_insts_per_Mpixel": insts * calls_per_step / mpix,
+                     "valu_wave_insts_per_block_lane": round(insts * 64.0 / (mpix * 1e6 / lanes_per_block), 1),
+                     "profile": "%s: rocprofv3 --pmc SQ_INSTS_VALU, bench.py --workload %s --content %s%s" % (
+                         rnd, wl, content, " --etc-strategy %s" % strat[1:] if wl.startswith("etc1") else "")}
+    with open(vpath, "w") as f:
+        json.dump(valu, f, indent=1, sort_keys=True)
+    print("valu_insts.json:", {k: v["valu_wave_insts_per_block_lane"] for k, v in valu.items()})
 
 
 if __name__ == "__main__":
