@@ -28,7 +28,7 @@ EXPORTS = [
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
     "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
-    "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -91,6 +91,8 @@ def lib():
             L.icamd_host_register.argtypes = [_vp, _sz]
             L.icamd_host_unregister.restype = _ci
             L.icamd_host_unregister.argtypes = [_vp]
+            L.icamd_pvrtc2_decompress.restype = _ci
+            L.icamd_pvrtc2_decompress.argtypes = [_u32, _vp, _sz, _vp, _sz]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -269,6 +271,15 @@ def pvrtc_encode_region_device(src, size, first_block, n_blocks, *, out=None, st
     if not _check(st, "icamd_pvrtc2_encode_region_device"):
         return None
     return out
+
+
+def pvrtc_decompress_host(blocks, size):
+    """icamd_pvrtc2_decompress (extension): bytes of size x size RGBA8, or None where the sizes are refused."""
+    import numpy as np
+    b = np.frombuffer(blocks, np.uint8)
+    out = np.zeros(size * size * 4, np.uint8)
+    st = lib().icamd_pvrtc2_decompress(size, b.ctypes.data, b.size, out.ctypes.data, out.size)
+    return out.tobytes() if _check(st, "icamd_pvrtc2_decompress") else None
 
 
 def pvrtc_workspace_size(size, n_images=1):

@@ -185,7 +185,7 @@ int staged_blockop(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_s
 extern "C" {
 #pragma GCC visibility push(default)
 
-const char *icamd_version(void) { return "image-compression_amd 0.1 (gfx950)"; }
+const char *icamd_version(void) { return "image-compression_amd 0.2 (gfx950)"; }
 const char *icamd_last_error(void) { return g_last_error.c_str(); }
 
 int icamd_device_count(void) {
@@ -578,6 +578,16 @@ int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width
   ICAMD_HIP(hipMemcpyAsync(out, g_staging.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
   ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
   return ICAMD_OK;
+}
+
+// EXTENSION (parity unpinned, see icamd_decode_device): host-buffer PVRTC 2bpp decode.  Kept apart from
+// icamd_decompress, which answers ICAMD_FALSE for PVRTC like the reference (pvrtc_compressor.cc:669-672).
+int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) {
+  if (!blocks || !out || !is_pow2(size) || size < 8) return ICAMD_FALSE;
+  if (blocks_size != (size_t)size * size / 4 || out_size != (size_t)size * size * 4) return ICAMD_FALSE;
+  return staged_blockop(blocks, blocks_size, out, out_size, false, [&](void *din, void *dout, hipStream_t s) {
+    return icamd_decode_device(ICAMD_PVRTC2, 0, size, size, 0, 1, 0, 0, din, dout, s);
+  });
 }
 
 // ---- compressed-domain operations

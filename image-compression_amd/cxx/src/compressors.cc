@@ -6,6 +6,7 @@
 // other error channel, and there is deliberately no CPU fallback.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -327,7 +328,17 @@ bool PvrtcCompressor::Compress(CompressedImage::Format format, uint32 height, ui
 }
 
 // pvrtc_compressor.cc:669-705: the reference implements none of these for PVRTC.
-bool PvrtcCompressor::Decompress(const CompressedImage &, std::vector<uint8> *) { return false; }
+// pvrtc_compressor.cc:669-672: `return false`.  Opt-in extension (ICAMD_PVRTC_DECOMPRESS_EXTENSION=1): the decoder
+// written from the encoder's own rules (include/ic_amd.h, icamd_pvrtc2_decompress; parity unpinned).
+bool PvrtcCompressor::Decompress(const CompressedImage &image, std::vector<uint8> *decompressed_buffer) {
+  const char *opt = std::getenv("ICAMD_PVRTC_DECOMPRESS_EXTENSION");
+  if (!opt || opt[0] != '1' || !decompressed_buffer || !IsValidCompressedImage(image)) return false;
+  const uint32 n = image.GetMetadata().uncompressed_width;
+  decompressed_buffer->assign((size_t)n * n * 4, 0);
+  return ReportStatus(icamd_pvrtc2_decompress(n, image.GetData(), image.GetDataSize(), decompressed_buffer->data(),
+                                              decompressed_buffer->size()),
+                      "icamd_pvrtc2_decompress");
+}
 bool PvrtcCompressor::Downsample(const CompressedImage &, CompressedImage *) { return false; }
 bool PvrtcCompressor::Pad(const CompressedImage &, uint32, uint32, CompressedImage *) { return false; }
 bool PvrtcCompressor::CompressAndPad(CompressedImage::Format, uint32, uint32, uint32, uint32, uint32, const uint8 *,

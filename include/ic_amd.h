@@ -157,6 +157,12 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
 int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                      const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size);
 
+/* EXTENSION (parity unpinned like icamd_decode_device(ICAMD_PVRTC2)): host-buffer PVRTC 2bpp decode of a size x size
+ * texture into size*size*4 RGBA bytes.  icamd_decompress itself keeps answering ICAMD_FALSE for PVRTC, like
+ * PvrtcCompressor::Decompress (pvrtc_compressor.cc:669-672); the C++ class of this repo only routes here when the
+ * environment variable ICAMD_PVRTC_DECOMPRESS_EXTENSION=1 is set. */
+int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size);
+
 /* ---- "next" rows 8f.2-4: compressed-domain operations on one image's block grid ----
  * Compressor::Pad (compressor.h:104-106; helper.h:393-477; pad functors dxtc.cc:594-696, etc.cc:645-698) for the
  * case that really pads: the source grid covers (compressed_height, compressed_width) pixels, the result

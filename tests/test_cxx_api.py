@@ -46,3 +46,17 @@ def test_cxx_api_transcript_matches_reference():
         for i, (a, b) in enumerate(zip(g, w)):
             assert a == b, "line %d:\n  ours: %s\n  ref:  %s" % (i + 1, a, b)
         assert len(g) == len(w)
+
+
+@pytest.mark.gpu
+def test_cxx_pvrtc_decompress_opt_in_extension():
+    """PvrtcCompressor::Decompress returns false like the reference (pvrtc_compressor.cc:669-672) unless
+    ICAMD_PVRTC_DECOMPRESS_EXTENSION=1 opts into the (parity-unpinned) decoder: with it, the only transcript lines
+    that change are PVRTC `decompress -> false` lines turning into `decompress -> true hash=...`."""
+    exe = os.path.join(BUILD, "api_driver_amd")
+    base = subprocess.run([exe], stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode().splitlines()
+    env = dict(os.environ, ICAMD_PVRTC_DECOMPRESS_EXTENSION="1")
+    ext = subprocess.run([exe], stdout=subprocess.PIPE, timeout=600, check=True, env=env).stdout.decode().splitlines()
+    assert len(base) == len(ext)
+    changed = [(a, b) for a, b in zip(base, ext) if a != b]
+    assert changed and all(a == "  decompress -> false" and b.startswith("  decompress -> true hash=") for a, b in changed)

@@ -311,6 +311,10 @@ def test_pvrtc_decoder_matches_oracle(pkg):
     assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 4096, 2048) is None
     assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 24, 24) is None
     assert pkg.decode_device(T.PVRTC2, enc.reshape(-1), 64, 64, padding_bytes_per_row=4) is None
+    # the host-buffer form of the extension (icamd_decompress itself answers false for PVRTC, like the reference)
+    small = T.oracle_encode(T.PVRTC2, T.s_mixed(64, 64, 4, index=9), 64, 64, 4)
+    assert pkg.pvrtc_decompress_host(small, 64) == T.oracle_decode(T.PVRTC2, small, 64, 64).tobytes()
+    assert pkg.pvrtc_decompress_host(small, 32) is None
 
 
 def test_pvrtc_call_sequences_host_api(pkg):
