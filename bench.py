@@ -256,10 +256,12 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        import datetime
+        tmo = datetime.timedelta(seconds=300)  # a wedged collective fails the run instead of hanging it
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+            dist.init_process_group(backend="nccl", device_id=device, timeout=tmo)  # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=tmo)
 
     def barrier():
         if distributed:
@@ -323,56 +325,59 @@ def main():
     # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
     gather = None
     if distributed and not args.no_gather:
-        counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
-            else [(r * batch, (r + 1) * batch) for r in range(world)]
-        counts = [e - b for b, e in counts]
-        comm = torch.cuda.Stream(device=device)
-        gathered = [sharding.alloc_gather_buffers(outs[0], counts, rank) for _ in range(2)]
-        enc_done = [torch.cuda.Event() for _ in range(2)]
-        gat_done = [torch.cuda.Event() for _ in range(2)]
+        try:
+            counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
+                else [(r * batch, (r + 1) * batch) for r in range(world)]
+            counts = [e - b for b, e in counts]
+            comm = torch.cuda.Stream(device=device)
+            gathered = [sharding.alloc_gather_buffers(outs[0], counts, rank) for _ in range(2)]
+            enc_done = [torch.cuda.Event() for _ in range(2)]
+            gat_done = [torch.cuda.Event() for _ in range(2)]
 
-        def gather_async(slot):
-            enc_done[slot].record(stream)
-            with torch.cuda.stream(comm):
-                comm.wait_event(enc_done[slot])
-                sharding.gather_to_root(outs[slot], gathered[slot], counts, rank, host_staged=args.backend == "gloo")
-                gat_done[slot].record(comm)
+            def gather_async(slot):
+                enc_done[slot].record(stream)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(enc_done[slot])
+                    sharding.gather_to_root(outs[slot], gathered[slot], counts, rank, host_staged=args.backend == "gloo")
+                    gat_done[slot].record(comm)
 
-        for slot in range(2):  # warm-up: communicator set-up, both buffers touched
-            step(outs[slot])
-            gather_async(slot)
-        torch.cuda.synchronize()
-        barrier()
-        g0 = time.perf_counter()
-        gather_async(0)
-        torch.cuda.synchronize()
-        barrier()
-        gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            slot = i & 1
-            stream.wait_event(gat_done[slot])  # the gather that last read this output buffer has finished
-            step(outs[slot])
-            gather_async(slot)                 # ... overlaps the encode of the next batch
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed_g = max_over_ranks(time.perf_counter() - t1)
-        ok = True
-        if rank == 0:
-            last = gathered[(args.steps - 1) & 1]
-            ok = bool(torch.equal(last[0], outs[(args.steps - 1) & 1]))
-        out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
-        gather = {"value_with_gather": round(pixels_per_step_all * args.steps / elapsed_g / 1e6, 1),
-                  "ms_per_step_with_gather": round(elapsed_g / args.steps * 1e3, 4),
-                  "gather_ms": round(gather_ms, 4),
-                  "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
-                  "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, "
-                            "overlapping the next batch's encode (backend %s)" % args.backend,
-                  "rank0_copy_matches": ok}
+            for slot in range(2):  # warm-up: communicator set-up, both buffers touched
+                step(outs[slot])
+                gather_async(slot)
+            torch.cuda.synchronize()
+            barrier()
+            g0 = time.perf_counter()
+            gather_async(0)
+            torch.cuda.synchronize()
+            barrier()
+            gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                slot = i & 1
+                stream.wait_event(gat_done[slot])  # the gather that last read this output buffer has finished
+                step(outs[slot])
+                gather_async(slot)                 # ... overlaps the encode of the next batch
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            elapsed_g = max_over_ranks(time.perf_counter() - t1)
+            ok = True
+            if rank == 0:
+                last = gathered[(args.steps - 1) & 1]
+                ok = bool(torch.equal(last[0], outs[(args.steps - 1) & 1]))
+            out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
+            gather = {"value_with_gather": round(pixels_per_step_all * args.steps / elapsed_g / 1e6, 1),
+                      "ms_per_step_with_gather": round(elapsed_g / args.steps * 1e3, 4),
+                      "gather_ms": round(gather_ms, 4),
+                      "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
+                      "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, "
+                                "overlapping the next batch's encode (backend %s)" % args.backend,
+                      "rank0_copy_matches": ok}
+        except Exception as e:  # the encode-only line must survive a failing gather (it is reported, not hidden)
+            gather = {"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)}
 
     tex = "%dx%d %s" % (size, size, "RGBA8" if comps == 4 else "RGB888")
     result = {
