@@ -41,7 +41,7 @@ def main():
         lines = text.splitlines()
         for name, e in meta.items():
             start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
-            end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+            end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))  # not the first s_endpgm
             mix = collections.Counter()
             for l in lines[start:end + 1]:
                 mm = re.match(r"\s+([vs]_\w+|global_\w+|ds_\w+|buffer_\w+|flat_\w+|scratch_\w+)", l)
