@@ -55,3 +55,29 @@ def test_no_gpu_means_a_loud_error_not_a_cpu_result(pkg):
     assert b"no HIP device" in pkg.lib().icamd_last_error()
     # argument errors are still reported the reference's way (false), before any device is needed
     assert pkg.lib().icamd_compress(T.DXTC, 2, T.RGB, 0, 8, 0, img.ctypes.data, out.ctypes.data, 32) == 1
+
+
+def test_header_is_plain_c_and_links_from_c(pkg, tmp_path):
+    """include/ic_amd.h is a C header (no C++ or torch types): a C99 translation unit that calls the host-only queries
+    compiles with gcc -std=c99 -Wall -Werror -pedantic, links against libic_amd.so and runs without a GPU."""
+    import subprocess
+    src = tmp_path / "abi_c99.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "ic_amd.h"
+int main(void) {
+  size_t n = icamd_compute_compressed_data_size(ICAMD_COMPRESSOR_DXTC, ICAMD_RGB, 61, 59);
+  int ok = icamd_supports_format(ICAMD_COMPRESSOR_ETC, ICAMD_RGB) && !icamd_supports_format(ICAMD_COMPRESSOR_ETC, ICAMD_RGBA);
+  /* a refused call needs no device: the reference's `false` */
+  int rc = icamd_compress(ICAMD_COMPRESSOR_DXTC, ICAMD_ETC_SMALLER_ERROR, ICAMD_RGB, 0, 8, 0, (const uint8_t *)"", (uint8_t *)&n, 8);
+  printf("%lu %d %d %lu %s\n", (unsigned long)n, ok, rc, (unsigned long)icamd_encoded_size(ICAMD_PVRTC2, 64, 64), icamd_version());
+  return 0;
+}
+''')
+    exe = tmp_path / "abi_c99"
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(T.ROOT, "include"),
+                           "-o", str(exe), str(src), "-L" + libdir, "-lic_amd", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=120, check=True).stdout.decode().split()
+    assert out[:4] == [str(T.oracle_size(T.DXTC, T.RGB, 61, 59)), "1", "1", str(64 * 64 // 4)]
