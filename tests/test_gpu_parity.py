@@ -721,7 +721,10 @@ def test_host_api_band_pipeline(pkg):
     for compressor, fmt, codec, h, w, pad, padded in (
             (T.DXTC, T.RGB, T.DXT1, 4096, 4096, 0, None), (T.DXTC, T.BGRA, T.DXT5, 2051, 3000, 7, None),
             (T.ETC, T.RGB, T.ETC1, 2999, 2048, 3, None), (T.DXTC, T.BGR, T.DXT1, 3001, 2500, 5, (3100, 2600)),
-            (T.DXTC, T.RGBA, T.DXT5, 1500, 4000, 0, (1500, 4100)), (T.ETC, T.RGB, T.ETC1, 2100, 1900, 0, (2133, 1900))):
+            (T.DXTC, T.RGBA, T.DXT5, 1500, 4000, 0, (1500, 4100)), (T.ETC, T.RGB, T.ETC1, 2100, 1900, 0, (2133, 1900)),
+            # more than 64 MiB of source: three 32 MiB bands on two streams, the last one ragged / with pad rows below
+            (T.DXTC, T.RGBA, T.DXT5, 5001, 4000, 0, None), (T.DXTC, T.RGB, T.DXT1, 6001, 4100, 4, (6100, 4100)),
+            (T.ETC, T.RGB, T.ETC1, 5999, 4099, 1, None)):
         comps = T.comps_of(fmt)
         img = T.s_smooth(h, w, comps, index=h % 13)
         img[: h // 3] = T.s_noise(h // 3, w, comps, index=w % 11)
