@@ -56,4 +56,35 @@ for it in range(60 * n_seeds):
             bad += 1
             print("MISMATCH", name, compressor, fmt, strategy, h, w, ph, pw, pad)
 print("block-op / decoder soak: %d checks, %d mismatches in total, %.1f s" % (ops, bad, time.time() - t0))
+
+# r02: DXT5 blocks that drive the O(1) alpha index search through every (alpha0, alpha1, alpha) on the DEVICE
+# (the CPU tier runs the same sweep through the host-emulated math), and PVRTC encode -> decode on random sizes
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_kernel_math_host as KM
+alphas = KM._alpha_blocks_exhaustive()
+g = np.random.Generator(np.random.PCG64(6))
+m = alphas.shape[0]
+chunk = 1 << 17
+for s0 in range(0, m, chunk):
+    a = alphas[s0:s0 + chunk]
+    k = a.shape[0]
+    img = np.zeros((4, 4 * k, 4), np.uint8)
+    img[..., :3] = g.integers(0, 256, (4, 4 * k, 3), dtype=np.uint8)
+    img[..., 3] = a.reshape(k, 4, 4).transpose(1, 0, 2).reshape(4, 4 * k)
+    out = pkg.encode_device(T.DXT5, torch.from_numpy(img).cuda(), 4, 4 * k, 4)
+    torch.cuda.synchronize()
+    if out.cpu().numpy().tobytes() != T.oracle_encode(T.DXT5, img, 4, 4 * k, 4, threads=16):
+        bad += 1
+        print("MISMATCH dxt5 alpha sweep chunk", s0)
+print("dxt5 alpha sweep on the device: %d blocks, %d mismatches in total, %.1f s" % (m, bad, time.time() - t0))
+for it in range(20 * n_seeds):
+    n = 8 << int(g.integers(0, 7))
+    words = g.integers(0, 256, n * n // 4, dtype=np.uint8) if it % 2 else \
+        np.frombuffer(T.oracle_encode(T.PVRTC2, T.soak_image(g, n, n, 4), n, n, 4), np.uint8)
+    dec = pkg.decode_device(T.PVRTC2, torch.from_numpy(words.copy()).cuda(), n, n)
+    torch.cuda.synchronize()
+    if dec.cpu().numpy().tobytes() != T.oracle_decode(T.PVRTC2, words.tobytes(), n, n).tobytes():
+        bad += 1
+        print("MISMATCH pvrtc decode", n, it)
+print("pvrtc decode soak done, %d mismatches in total, %.1f s" % (bad, time.time() - t0))
 sys.exit(1 if bad else 0)
