@@ -37,6 +37,16 @@ def slab_geometry(height, width, components, row_stride_bytes, block_bytes, worl
             "dst_bytes": (b1 - b0) * cols * block_bytes}
 
 
+def encode_slab(encode_fn, src, height, width, components, row_stride_bytes, block_bytes, world_size, rank):
+    """This rank's slab of ONE DXT/ETC image: encode_fn(slab_bytes, pixel_rows, grid_rows) -> uint8 tensor of the slab's
+    blocks, called with the rank's byte range of `src` (a flat uint8 tensor).  Ranks whose share is empty (fewer block
+    rows than ranks) get an empty tensor instead of a refused zero-height encode.  Returns (blocks, geometry)."""
+    geo = slab_geometry(height, width, components, row_stride_bytes, block_bytes, world_size, rank)
+    if geo["pixel_rows"] == 0:
+        return torch.empty((0,), dtype=torch.uint8, device=src.device), geo
+    return encode_fn(src[geo["src_offset_bytes"]:], geo["pixel_rows"], geo["block_rows"] * 4), geo
+
+
 def pvrtc_region(size, world_size, rank):
     """One PVRTC 2 bpp texture (size x size) sharded over `world_size` (a power of two) ranks by Z-order range: rank r
     owns blocks [r * n, (r + 1) * n) of the output, n = blocks / world_size -- a rectangle of the block grid

@@ -67,6 +67,17 @@ def _worker(rank, world, port, results):
     ok &= slab == whole[geo["dst_offset_bytes"]: geo["dst_offset_bytes"] + geo["dst_bytes"]]
     sizes = [sh.slab_geometry(h, w, comps, stride, 16, world, r)["dst_bytes"] for r in range(world)]
     ok &= sum(sizes) == len(whole)
+    # (2b) fewer block rows than ranks: the empty slab is an empty tensor, the others still tile the image
+    h1, w1 = 3, 21
+    img1 = T.s_mixed(h1, w1, 3, index=8)
+    flat1 = torch.from_numpy(np.ascontiguousarray(img1).reshape(-1))
+
+    def enc_slab(slab, rows, grid_rows):
+        return torch.from_numpy(np.frombuffer(T.oracle_encode(T.ETC1, slab.numpy(), rows, w1, 3, gh=grid_rows, gw=w1), np.uint8).copy())
+    blocks1, geo1 = sh.encode_slab(enc_slab, flat1, h1, w1, 3, w1 * 3, 8, world, rank)
+    whole1 = T.oracle_encode(T.ETC1, img1, h1, w1, 3)
+    ok &= blocks1.numpy().tobytes() == whole1[geo1["dst_offset_bytes"]: geo1["dst_offset_bytes"] + geo1["dst_bytes"]]
+    ok &= (blocks1.numel() == 0) == (geo1["block_rows"] == 0)
     # (3) gather_to_root: config 4's texture_range split, equal and unequal per-rank counts, rank-0 receive buffers
     for n in (8, 7):
         counts = [e - b for b, e in (sh.texture_range(n, world, r) for r in range(world))]
