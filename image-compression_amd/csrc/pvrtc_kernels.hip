@@ -139,21 +139,59 @@ constexpr int kMorphBlocksPerLane = 4;
 // LDS of a morph workgroup: the per-lane pixel stash for index lookups, 8 planes x 256 lanes x 16 B = 32 KiB
 constexpr uint32_t kLdsDwords = 8 * kMorphLanes * 4;
 
-template <int kBlocksPerLane>
+template <int kBlocksPerLane, bool DENSE = false>
 __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds) {
   const uint32_t k0 = wg * (kMorphLanes * kBlocksPerLane) + threadIdx.x;
   const uint32_t n = L.size, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
+  const uint32_t lane = threadIdx.x & 63u;
   Stash32 stash;
   stash.base = lds + threadIdx.x * 4u;  // [plane][lane][4 dwords]
   stash.row_dwords = kMorphLanes * 4;
+  stash.filled = DENSE;
+  // DENSE (block grids at least 64 columns wide: a wave's 64 blocks are one 2 KiB run per pixel row): lane l fetches
+  // the l-th and the (64 + l)-th 16-byte piece of that run -- two fully dense 1 KiB accesses per row instead of two
+  // half-dense 2 KiB ones -- and the pieces are handed to the lanes that own them through the LDS stash, which the
+  // index lookups need filled anyway (the owner reads its 32 pixels back with 8 ds_read_b128).  The kernel is bound
+  // by its memory accesses, not by issue (removing a quarter of its VALU work moved it by 1 %): r02 A/B 0.533 -> 0.510 ms
+  // for the whole codec on noise, 0.529 -> 0.506 on flat, 0.494 -> 0.485 on smooth (profiles/r02_ab_morph_dense.log).
   auto fetch = [&](uint32_t k, uint32_t px[32]) {
-    const uint32_t image = k >> L.log2_bpi, b = k & bpi_mask;
+    const uint32_t kb = DENSE ? k - lane : k;  // DENSE: first block of the wave
+    const uint32_t image = kb >> L.log2_bpi, b = kb & bpi_mask;
     const uint32_t by = b >> L.log2_bw, bx = b & bw_mask;
     const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
-    load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+    if (DENSE) {
+      const uint32_t *row0 = img + (size_t)(by * 4u) * n + bx * 8u + lane * 4u;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const U4 a = load_stream(reinterpret_cast<const U4 *>(row0 + (size_t)y * n));
+        const U4 c = load_stream(reinterpret_cast<const U4 *>(row0 + (size_t)y * n + 256));
+        px[8 * y + 0] = a.x; px[8 * y + 1] = a.y; px[8 * y + 2] = a.z; px[8 * y + 3] = a.w;
+        px[8 * y + 4] = c.x; px[8 * y + 5] = c.y; px[8 * y + 6] = c.z; px[8 * y + 7] = c.w;
+      }
+    } else {
+      load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+    }
   };
-  auto reduce = [&](uint32_t k, const uint32_t px[32]) {
+  auto reduce = [&](uint32_t k, uint32_t px[32]) {
     const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)(k >> L.log2_bpi) * L.src_image_stride);
+    if (DENSE) {
+      // piece A of row y = columns 4 (lane & 1) .. of block (lane >> 1): plane 2 y + (lane & 1) of that owner's slot;
+      // piece B the same for block 32 + (lane >> 1)
+      uint32_t *wave_lds = lds + (threadIdx.x & ~63u) * 4u;
+      uint32_t *slot = wave_lds + (lane & 1u) * stash.row_dwords + (lane >> 1) * 4u;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        *reinterpret_cast<uint4 *>(slot + (2 * y) * stash.row_dwords) =
+            make_uint4(px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3]);
+        *reinterpret_cast<uint4 *>(slot + (2 * y) * stash.row_dwords + 32 * 4) =
+            make_uint4(px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7]);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(stash.base + q * stash.row_dwords);
+        px[4 * q] = v.x; px[4 * q + 1] = v.y; px[4 * q + 2] = v.z; px[4 * q + 3] = v.w;
+      }
+    }
     uint32_t a, c;
     pvrtc_extremes(px, img[0], stash, a, c);
     L.ab[k] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
@@ -181,6 +219,11 @@ __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, 
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_kernel(PvrtcLaunch L) {
   __shared__ uint32_t lds[kLdsDwords];
   pvrtc2_morph<kMorphBlocksPerLane>(L, blockIdx.x, lds);
+}
+// block grids at least 64 columns wide (textures of 512^2 and more): dense row accesses, transposed through the stash
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_dense_kernel(PvrtcLaunch L) {
+  __shared__ uint32_t lds[kLdsDwords];
+  pvrtc2_morph<kMorphBlocksPerLane, true>(L, blockIdx.x, lds);
 }
 // small launches (a few textures of <= 1024^2): one block per lane, four times as many workgroups
 extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_small_kernel(PvrtcLaunch L) {
@@ -405,6 +448,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     const uint32_t per_wg = kMorphLanes * (small ? 1 : kMorphBlocksPerLane);
     const dim3 gm((Q.total_blocks + per_wg - 1) / per_wg), ge((Q.total_strips + kEncodeLanes - 1) / kEncodeLanes);
     if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
+    else if (Q.log2_bw >= 6) hipLaunchKernelGGL(icamd_pvrtc2_morph_dense_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
     else hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, Q);
   }
