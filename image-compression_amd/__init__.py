@@ -10,11 +10,20 @@ importlib; the package registers itself as `image_compression_amd`.
 """
 import ctypes
 import os
+import threading
 
 import torch  # must precede CDLL: libic_amd.so then binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("ICAMD_LIB_PATH", os.path.join(_HERE, "libic_amd.so"))  # override: A/B experiments only
+_DEFAULT_LIB_PATH = os.path.join(_HERE, "libic_amd.so")
+# A/B experiments only: ICAMD_LIB_PATH swaps the product library for another build, and is honoured ONLY together with
+# ICAMD_ALLOW_LIB_OVERRIDE=1 (a stray variable must not silently redirect a benchmark); bench.py records LIB_PATH and
+# LIB_OVERRIDDEN in its output line.
+if "ICAMD_LIB_PATH" in os.environ and os.environ.get("ICAMD_ALLOW_LIB_OVERRIDE") != "1":
+    raise ImportError("ICAMD_LIB_PATH is set (%s) but ICAMD_ALLOW_LIB_OVERRIDE=1 is not: refusing to load a library "
+                      "other than %s" % (os.environ["ICAMD_LIB_PATH"], _DEFAULT_LIB_PATH))
+LIB_PATH = os.environ.get("ICAMD_LIB_PATH", _DEFAULT_LIB_PATH)
+LIB_OVERRIDDEN = os.path.realpath(LIB_PATH) != os.path.realpath(_DEFAULT_LIB_PATH)
 
 # enums of include/ic_amd.h
 COMPRESSOR_DXTC, COMPRESSOR_ETC, COMPRESSOR_PVRTC = 0, 1, 2
@@ -33,6 +42,7 @@ EXPORTS = [
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
 _lib = None
+_tls = threading.local()  # per-thread state mirrored from the C side (the PVRTC workspace override is thread-local there)
 
 
 class BackendError(RuntimeError):
@@ -82,7 +92,7 @@ def lib():
         L.icamd_compress_batch.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp, _ci, _vp]
         L.icamd_pvrtc2_encode_region_device.restype = _ci
         L.icamd_pvrtc2_encode_region_device.argtypes = [_u32, _u32, _u32, _vp, _vp, _vp]
-        if "ICAMD_LIB_PATH" not in os.environ or hasattr(L, "icamd_pvrtc2_workspace_size"):  # older A/B builds lack it
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_workspace_size"):  # older A/B builds lack it
             L.icamd_pvrtc2_workspace_size.restype = _sz
             L.icamd_pvrtc2_workspace_size.argtypes = [_u32, _u32]
             L.icamd_pvrtc2_set_workspace.restype = _ci
@@ -290,10 +300,18 @@ def pvrtc_set_workspace(workspace):
     """Caller-owned PVRTC scratch for the calls that follow on this thread (a torch.uint8 CUDA tensor of at least
     pvrtc_workspace_size bytes; needed to capture PVRTC launches into a HIP graph).  None: the library's own buffer."""
     if workspace is None:
+        _tls.workspace = None
         return _check(lib().icamd_pvrtc2_set_workspace(None, 0), "icamd_pvrtc2_set_workspace")
     assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous()
-    return _check(lib().icamd_pvrtc2_set_workspace(ctypes.c_void_p(workspace.data_ptr()), workspace.numel()),
-                  "icamd_pvrtc2_set_workspace")
+    if workspace.device.index not in (None, torch.cuda.current_device()):
+        raise ValueError("PVRTC workspace lives on %s but the current device is cuda:%d"
+                         % (workspace.device, torch.cuda.current_device()))
+    ok = _check(lib().icamd_pvrtc2_set_workspace(ctypes.c_void_p(workspace.data_ptr()), workspace.numel()),
+                "icamd_pvrtc2_set_workspace")
+    # the C side keeps only the raw pointer (per host thread): hold the tensor until the override is cleared, so that
+    # a caller dropping its reference cannot leave the library writing into freed memory
+    _tls.workspace = workspace if ok else None
+    return ok
 
 
 def compress_batch_host(compressor, fmt, images, height, width, devices, *, padding_bytes_per_row=0,

@@ -59,7 +59,8 @@ struct Staging {
   size_t cap_in = 0, cap_out = 0;
   void *h_in = nullptr, *h_out = nullptr;  // pinned host mirrors (batch workers only)
   size_t cap_hin = 0, cap_hout = 0;
-  ~Staging() { drop(); }
+  // No destructor: a Staging is never destroyed (see TlsStaging below) -- no HIP call may run from a thread_local or
+  // static destructor, where the HIP runtime can already be gone.
   void drop() {
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
@@ -107,12 +108,13 @@ struct Staging {
     return ICAMD_OK;
   }
 };
-thread_local Staging g_staging;
 
-// icamd_compress_batch runs on short-lived worker threads: their staging (device buffers, pinned host mirrors,
-// stream) comes from this process-wide pool and goes back to it, so repeated batches allocate nothing.
-// (Heap-allocated and never destroyed: at process exit the HIP runtime may already be gone.)
-std::mutex g_pool_mutex;
+// Every Staging lives in (or is on loan from) this process-wide pool: icamd_compress_batch's short-lived worker
+// threads take one and give it back, so repeated batches allocate nothing, and a thread's own staging (tls_staging())
+// returns to the pool when the thread ends instead of being destroyed.  The pool itself is heap-allocated and never
+// destroyed: at process exit the HIP runtime may already be gone, so nothing here calls into it from a destructor --
+// the driver reclaims device memory and streams with the process.
+std::mutex &g_pool_mutex = *new std::mutex();
 std::vector<std::unique_ptr<Staging>> &g_pool = *new std::vector<std::unique_ptr<Staging>>();
 
 std::unique_ptr<Staging> pool_take(int device) {
@@ -129,6 +131,25 @@ void pool_give(std::unique_ptr<Staging> s) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   g_pool.push_back(std::move(s));
 }
+
+// The calling thread's staging for the host-buffer entry points: borrowed from the pool on first use (any device --
+// Staging::ensure re-targets it), handed back -- not freed -- by the thread_local destructor.
+struct TlsStaging {
+  Staging *p = nullptr;
+  Staging &get() {
+    if (!p) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      p = pool_take(dev).release();
+    }
+    return *p;
+  }
+  ~TlsStaging() {
+    if (p) pool_give(std::unique_ptr<Staging>(p));  // no HIP call here
+  }
+};
+thread_local TlsStaging g_tls_staging;
+Staging &tls_staging() { return g_tls_staging.get(); }
 
 int require_device() {
   int n = 0;
@@ -166,17 +187,45 @@ template <typename F>
 int staged_blockop(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_size, bool in_place, F &&run) {
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  rc = g_staging.ensure(std::max<size_t>(in_size, 1), std::max<size_t>(out_size, 1));
+  Staging &st = tls_staging();
+  rc = st.ensure(std::max<size_t>(in_size, 1), std::max<size_t>(out_size, 1));
   if (rc != ICAMD_OK) return rc;
-  hipStream_t s = g_staging.stream;
-  ICAMD_HIP(hipMemcpyAsync(g_staging.d_in, in, in_size, hipMemcpyHostToDevice, s), "H2D copy");
-  rc = run(g_staging.d_in, g_staging.d_out, s);
+  hipStream_t s = st.stream;
+  ICAMD_HIP(hipMemcpyAsync(st.d_in, in, in_size, hipMemcpyHostToDevice, s), "H2D copy");
+  rc = run(st.d_in, st.d_out, s);
   if (rc != ICAMD_OK) {
     (void)hipStreamSynchronize(s);
     return rc;
   }
-  ICAMD_HIP(hipMemcpyAsync(out, in_place ? g_staging.d_in : g_staging.d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
+  ICAMD_HIP(hipMemcpyAsync(out, in_place ? st.d_in : st.d_out, out_size, hipMemcpyDeviceToHost, s), "D2H copy");
   ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
+  return ICAMD_OK;
+}
+
+// PVRTC branch of icamd_encode_device.  internal_workspace: the call comes from the library's own host-buffer path
+// (its staging stream), which must not borrow the workspace a caller registered for its own streams / graphs.
+int pvrtc_encode_device_impl(int src_components, uint32_t height, uint32_t width, uint32_t row_stride_bytes,
+                             uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
+                             const void *d_src, void *d_dst, hipStream_t stream, bool internal_workspace) {
+  // preconditions of PvrtcCompressor::Compress, pvrtc.cc:636-650 (source always read as RGBA8888)
+  if (!is_pow2(width) || !is_pow2(height) || width != height || width % 8 || height % 4) return ICAMD_FALSE;
+  // the reference sizes its output with the uint32 product width * height / 4 (pvrtc.cc:631-634), which wraps to 0 at
+  // 65536^2 -- it would then write 2^30 bytes into a zero-byte buffer; refused here
+  if (width >= 65536u) return ICAMD_FALSE;
+  if (src_components != 4 || row_stride_bytes != width * 4u) return ICAMD_FALSE;
+  if (reinterpret_cast<uintptr_t>(d_src) % 16u || reinterpret_cast<uintptr_t>(d_dst) % 8u ||
+      (n_images > 1 && (src_image_stride_bytes % 16u || dst_image_stride_bytes % 8u)))
+    return fail(ICAMD_ERR_ARG, "PVRTC: source must be 16-byte aligned, output 8-byte aligned");
+  icamd::PvrtcParams P;
+  P.src = static_cast<const uint8_t *>(d_src);
+  P.dst = static_cast<uint8_t *>(d_dst);
+  P.src_image_stride = src_image_stride_bytes;
+  P.dst_image_stride = dst_image_stride_bytes;
+  P.size = width;
+  P.log2_size = ilog2(width);
+  P.n_images = n_images;
+  P.internal_workspace = internal_workspace;
+  ICAMD_HIP(icamd::launch_pvrtc2(P, stream), "launch pvrtc2");
   return ICAMD_OK;
 }
 
@@ -185,7 +234,7 @@ int staged_blockop(const uint8_t *in, size_t in_size, uint8_t *out, size_t out_s
 extern "C" {
 #pragma GCC visibility push(default)
 
-const char *icamd_version(void) { return "image-compression_amd 0.2 (gfx950)"; }
+const char *icamd_version(void) { return "image-compression_amd 0.3 (gfx950)"; }
 const char *icamd_last_error(void) { return g_last_error.c_str(); }
 
 int icamd_device_count(void) {
@@ -237,24 +286,9 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
   if (rc != ICAMD_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 
-  if (codec == ICAMD_PVRTC2) {
-    // preconditions of PvrtcCompressor::Compress, pvrtc.cc:636-650 (source always read as RGBA8888)
-    if (!is_pow2(width) || !is_pow2(height) || width != height || width % 8 || height % 4) return ICAMD_FALSE;
-    if (src_components != 4 || row_stride_bytes != width * 4u) return ICAMD_FALSE;
-    if (reinterpret_cast<uintptr_t>(d_src) % 16u || reinterpret_cast<uintptr_t>(d_dst) % 8u ||
-        (n_images > 1 && (src_image_stride_bytes % 16u || dst_image_stride_bytes % 8u)))
-      return fail(ICAMD_ERR_ARG, "PVRTC: source must be 16-byte aligned, output 8-byte aligned");
-    icamd::PvrtcParams P;
-    P.src = static_cast<const uint8_t *>(d_src);
-    P.dst = static_cast<uint8_t *>(d_dst);
-    P.src_image_stride = src_image_stride_bytes;
-    P.dst_image_stride = dst_image_stride_bytes;
-    P.size = width;
-    P.log2_size = ilog2(width);
-    P.n_images = n_images;
-    ICAMD_HIP(icamd::launch_pvrtc2(P, stream), "launch pvrtc2");
-    return ICAMD_OK;
-  }
+  if (codec == ICAMD_PVRTC2)
+    return pvrtc_encode_device_impl(src_components, height, width, row_stride_bytes, n_images, src_image_stride_bytes,
+                                    dst_image_stride_bytes, d_src, d_dst, stream, false);
   if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1) return fail(ICAMD_ERR_ARG, "unknown codec");
   if (codec == ICAMD_DXT5 && src_components != 4) return fail(ICAMD_ERR_ARG, "DXT5 needs a 4-component source");
   if (row_stride_bytes < width * (uint32_t)src_components) return fail(ICAMD_ERR_ARG, "row stride smaller than a row");
@@ -356,6 +390,7 @@ int icamd_compress_device(int compressor, int etc_strategy, int format,
     if (!is_pow2(width) || !is_pow2(height) || width != height) return ICAMD_FALSE;
     if (padding_bytes_per_row != 0) return ICAMD_FALSE;
     if (width % 8 != 0 || height % 4 != 0) return ICAMD_FALSE;
+    if (width >= 65536u) return ICAMD_FALSE;  // the reference's uint32 width * height / 4 wraps (see pvrtc_encode_device_impl)
     if (out_size != (size_t)(width * height / 4)) return ICAMD_FALSE;
     return icamd_encode_device(ICAMD_PVRTC2, 0, 4, 0, height, width, height, width, width * 4u, 1, 0, 0,
                                d_buffer, d_out, hip_stream);
@@ -398,6 +433,7 @@ static int compress_host_common(Staging &st, bool pinned, bool and_pad, int comp
     // pvrtc.cc:636-667
     if (!is_pow2(width) || !is_pow2(height) || width != height || padding_bytes_per_row != 0) return ICAMD_FALSE;
     if (width % 8 != 0 || height % 4 != 0) return ICAMD_FALSE;
+    if (width >= 65536u) return ICAMD_FALSE;  // the reference's uint32 width * height / 4 wraps (see pvrtc_encode_device_impl)
     if (out_size != (size_t)(width * height / 4)) return ICAMD_FALSE;
   } else {
     if (!resolve_codec(compressor, format, &codec, &comps, &swap)) return ICAMD_FALSE;  // dxtc.cc:735-750, etc.cc:747-758
@@ -424,7 +460,7 @@ static int compress_host_common(Staging &st, bool pinned, bool and_pad, int comp
   if (pvrtc) {
     hipStream_t s = st.stream;
     ICAMD_HIP(hipMemcpyAsync(d_in, h_src, in_bytes, hipMemcpyHostToDevice, s), "H2D copy");
-    rc = icamd_encode_device(ICAMD_PVRTC2, 0, 4, 0, height, width, height, width, width * 4u, 1, 0, 0, d_in, d_out, s);
+    rc = pvrtc_encode_device_impl(4, height, width, width * 4u, 1, 0, 0, d_in, d_out, s, true);
     if (rc != ICAMD_OK) {
       (void)hipStreamSynchronize(s);
       return rc;
@@ -465,14 +501,14 @@ static int compress_host_common(Staging &st, bool pinned, bool and_pad, int comp
 
 int icamd_compress(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
                    uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out, size_t out_size) {
-  return compress_host_common(g_staging, false, false, compressor, etc_strategy, format, height, width, height, width,
+  return compress_host_common(tls_staging(), false, false, compressor, etc_strategy, format, height, width, height, width,
                               padding_bytes_per_row, buffer, out, out_size);
 }
 
 int icamd_compress_and_pad(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
                            uint32_t padded_height, uint32_t padded_width, uint32_t padding_bytes_per_row,
                            const uint8_t *buffer, uint8_t *out, size_t out_size) {
-  return compress_host_common(g_staging, false, true, compressor, etc_strategy, format, height, width, padded_height,
+  return compress_host_common(tls_staging(), false, true, compressor, etc_strategy, format, height, width, padded_height,
                               padded_width, padding_bytes_per_row, buffer, out, out_size);
 }
 
@@ -564,18 +600,18 @@ int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width
   if (out_size != need) return ICAMD_FALSE;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  rc = g_staging.ensure(blocks_size, need);
+  Staging &st = tls_staging();
+  rc = st.ensure(blocks_size, need);
   if (rc != ICAMD_OK) return rc;
-  hipStream_t s = g_staging.stream;
-  ICAMD_HIP(hipMemcpyAsync(g_staging.d_in, blocks, blocks_size, hipMemcpyHostToDevice, s), "H2D copy");
-  if (padding_bytes_per_row) ICAMD_HIP(hipMemsetAsync(g_staging.d_out, 0, need, s), "memset");
-  rc = icamd_decode_device(codec, swap, height, width, padding_bytes_per_row, 1, 0, 0, g_staging.d_in,
-                           g_staging.d_out, s);
+  hipStream_t s = st.stream;
+  ICAMD_HIP(hipMemcpyAsync(st.d_in, blocks, blocks_size, hipMemcpyHostToDevice, s), "H2D copy");
+  if (padding_bytes_per_row) ICAMD_HIP(hipMemsetAsync(st.d_out, 0, need, s), "memset");
+  rc = icamd_decode_device(codec, swap, height, width, padding_bytes_per_row, 1, 0, 0, st.d_in, st.d_out, s);
   if (rc != ICAMD_OK) {
     (void)hipStreamSynchronize(s);
     return rc;
   }
-  ICAMD_HIP(hipMemcpyAsync(out, g_staging.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
+  ICAMD_HIP(hipMemcpyAsync(out, st.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
   ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
   return ICAMD_OK;
 }

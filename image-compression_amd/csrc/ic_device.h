@@ -272,7 +272,8 @@ template <int COMPS>
 ICAMD_DEV void load_block_interior(const uint8_t *__restrict__ base, uint32_t off, uint32_t stride, uint32_t px[16]) {
   ICAMD_UNROLL
   for (int y = 0; y < 4; ++y) {
-    // the row advance stays in the 32-bit lane offset (launch_tiled guarantees 1024 * stride < 2^32)
+    // the row advance stays in the 32-bit lane offset (launch_tiled: tiles are 256 x 1 when 1024 * stride >= 2^32, and
+    // rows too long even for three strides take the 64-bit gather, GridParams::force_gather)
     const uint8_t *row = base + (uint32_t)(off + (uint32_t)y * stride);
     if (COMPS == 4) {
       U4 v = load_stream(reinterpret_cast<const U4 *>(row));

@@ -68,6 +68,8 @@ struct PvrtcParams {
   // region_blocks != 0: encode only the blocks [region_first, region_first + region_blocks) of ONE image's Z-order
   // output (a power-of-two, aligned range = a rectangle of blocks); dst receives just those 8 * region_blocks bytes
   uint32_t region_first = 0, region_blocks = 0;
+  // the library's own host-buffer path: never borrow the caller-owned workspace (icamd_pvrtc2_set_workspace)
+  bool internal_workspace = false;
 };
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream);
 // Scratch the PVRTC encoder needs between its two kernels for n_images size x size textures (8 bytes per block of one

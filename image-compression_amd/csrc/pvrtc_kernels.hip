@@ -24,6 +24,9 @@
 // per lane (+37 % modulation work) removes every dependency between lanes.
 // Launch order is morph(all images of a group) then encode(same group), groups as large as the workspace allows
 // (see launch_pvrtc2); toroidal wrap (pvrtc.cc:216-227,416-423) is applied to block / pixel coordinates.
+#include <mutex>
+#include <vector>
+
 #include "ic_launch.h"
 #include "ic_amd.h"
 #include "pvrtc_block.h"
@@ -59,12 +62,14 @@ struct Workspace {
   bool in_flight = false;
   void *user_ptr = nullptr;  // caller-owned workspace (thread-local override); no allocation, no events
   size_t user_bytes = 0;
-  ~Workspace() {
-    if (ptr) (void)hipFree(ptr);
-    if (done) (void)hipEventDestroy(done);
-  }
-  hipError_t acquire(size_t bytes, hipStream_t stream, void **out) {
-    if (user_ptr) {
+  bool using_user = false;   // between acquire and release: the caller-owned workspace is the one in use
+  // No destructor: a Workspace is never destroyed (TlsWorkspace below parks it in a leaked process-wide list when its
+  // thread ends) -- no HIP call may run from a thread_local destructor, where the runtime can already be gone.
+  // internal_only: the library's own staging-stream calls (icamd_compress of a PVRTC image) never borrow the
+  // caller-owned workspace -- that one belongs to the caller's streams and graphs.
+  hipError_t acquire(size_t bytes, hipStream_t stream, void **out, bool internal_only = false) {
+    using_user = user_ptr && !internal_only;
+    if (using_user) {
       if (bytes > user_bytes) return hipErrorInvalidValue;
       *out = user_ptr;
       return hipSuccess;
@@ -96,13 +101,38 @@ struct Workspace {
     return hipSuccess;
   }
   hipError_t release(hipStream_t stream) {
-    if (user_ptr) return hipSuccess;
+    if (using_user) return hipSuccess;
     last_stream = stream;
     in_flight = true;
     return hipEventRecord(done, stream);
   }
 };
-thread_local Workspace g_workspace;
+// Parked workspaces of threads that ended (leaked on purpose at process exit, re-used by later threads).
+std::mutex &g_ws_mutex = *new std::mutex();
+std::vector<Workspace *> &g_ws_parked = *new std::vector<Workspace *>();
+struct TlsWorkspace {
+  Workspace *p = nullptr;
+  Workspace &get() {
+    if (!p) {
+      std::lock_guard<std::mutex> lock(g_ws_mutex);
+      if (!g_ws_parked.empty()) {
+        p = g_ws_parked.back();
+        g_ws_parked.pop_back();
+      } else {
+        p = new Workspace();
+      }
+    }
+    return *p;
+  }
+  ~TlsWorkspace() {
+    if (!p) return;
+    p->user_ptr = nullptr;  // the override was this thread's
+    p->user_bytes = 0;
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    g_ws_parked.push_back(p);  // no HIP call here
+  }
+};
+thread_local TlsWorkspace g_tls_workspace;
 
 // images of one launch pair: as many as 4 GiB of pixels (and the 32-bit block index) allow
 uint64_t pvrtc_group(uint32_t size, uint32_t n_images) {
@@ -358,7 +388,8 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
       (uint64_t)P.region_first + P.region_blocks > (1ull << log2_bpi))
     return hipErrorInvalidValue;
   uint2 *ab = nullptr;
-  hipError_t e = g_workspace.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
+  Workspace &ws = g_tls_workspace.get();
+  hipError_t e = ws.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
   if (e != hipSuccess) return e;
   (void)hipGetLastError();
   PvrtcLaunch L;
@@ -377,7 +408,9 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   L.z_first = P.region_first;
   L.log2_strip = log2_rh < 3 ? log2_rh : 3;
   while (L.log2_strip > 0 && (P.region_blocks >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
-  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip) ? 1u : 0u;
+  // the staged write-out issues 16-byte stores: only when the region's output is 16-byte aligned (8 is the contract)
+  const bool dst16 = reinterpret_cast<uintptr_t>(P.dst) % 16u == 0;
+  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip && dst16) ? 1u : 0u;
   L.total_blocks = 1u << log2_bpi;
   L.total_strips = P.region_blocks >> L.log2_strip;
   const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
@@ -385,7 +418,7 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   hipLaunchKernelGGL(icamd_pvrtc2_morph_rect_kernel, gm, dim3(kMorphLanes), 0, stream, L);
   hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
   e = hipGetLastError();
-  const hipError_t e2 = g_workspace.release(stream);
+  const hipError_t e2 = ws.release(stream);
   return e != hipSuccess ? e : e2;
 }
 
@@ -408,7 +441,8 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   // thread: stream-ordered pool memory (hipMallocAsync) proved unusable for producer->consumer kernels on ROCm 7.2
   // (a reused pool block was observed zero-filled underneath the first kernel; scripts/coh_test.hip).
   uint2 *ab = nullptr;
-  hipError_t e = g_workspace.acquire((size_t)(bpi * group * sizeof(uint2)), stream, reinterpret_cast<void **>(&ab));
+  Workspace &ws = g_tls_workspace.get();
+  hipError_t e = ws.acquire((size_t)(bpi * group * sizeof(uint2)), stream, reinterpret_cast<void **>(&ab), P.internal_workspace);
   if (e != hipSuccess) return e;
   (void)hipGetLastError();
   PvrtcLaunch L;
@@ -428,7 +462,9 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   L.rx0 = L.ry0 = L.z_first = 0;
   L.log2_rw = L.log2_bw;
   L.log2_rblocks = L.log2_bpi;
-  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip) ? 1u : 0u;
+  // the staged write-out issues 16-byte stores: taken only when every image's output is 16-byte aligned (the
+  // contract asks for 8); otherwise each block is stored on its own, 8 bytes at its Z-order slot
+  const bool dst16 = reinterpret_cast<uintptr_t>(P.dst) % 16u == 0 && (P.n_images == 1 || P.dst_image_stride % 16u == 0);
   for (uint64_t first = 0; first < P.n_images; first += group) {
     const uint64_t count = (P.n_images - first < group) ? P.n_images - first : group;
     // images [i0, i0 + cnt) of this chunk as one launch descriptor
@@ -438,7 +474,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
       Q.dst = P.dst + (first + i0) * P.dst_image_stride;
       Q.ab = ab + i0 * bpi;
       Q.log2_strip = log2_strip;
-      Q.stage_stores = (log2_strip >= 1 && Q.log2_rw >= log2_strip) ? 1u : 0u;
+      Q.stage_stores = (log2_strip >= 1 && Q.log2_rw >= log2_strip && dst16) ? 1u : 0u;
       Q.total_blocks = (uint32_t)(bpi * cnt);
       Q.total_strips = Q.total_blocks >> log2_strip;
       return Q;
@@ -453,7 +489,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, Q);
   }
   e = hipGetLastError();
-  const hipError_t e2 = g_workspace.release(stream);
+  const hipError_t e2 = ws.release(stream);
   return e != hipSuccess ? e : e2;
 }
 
@@ -462,8 +498,9 @@ size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images) {
   return (size_t)((uint64_t)(size / 8) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));
 }
 void pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
-  g_workspace.user_ptr = d_workspace;
-  g_workspace.user_bytes = d_workspace ? bytes : 0;
+  Workspace &ws = g_tls_workspace.get();
+  ws.user_ptr = d_workspace;
+  ws.user_bytes = d_workspace ? bytes : 0;
 }
 
 }  // namespace icamd
