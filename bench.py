@@ -86,6 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained-run leg (N = 1)")
+    ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-launch leg (N = 1)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: debugging only (several ranks sharing one GPU; the gather is staged through the host)")
     args = ap.parse_args(argv)
@@ -227,6 +230,180 @@ def host_api_leg(pkg, T, codec, size, strategy):
     except Exception as e:
         res["page_locked"] = "unavailable: %s" % e
     return res
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return None if n == 0 else (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2]))
+
+
+class SclkSampler:
+    """Samples the GPU core clock the driver reports (sysfs hwmon freq1_input / pp_dpm_sclk, else `rocm-smi`) from a
+    host thread while a timed leg runs.  Secondary evidence next to the in-kernel clock probe; absent sources are
+    reported as such, never guessed."""
+
+    def __init__(self, period_s=0.02):
+        import glob
+        import threading
+        self.period = period_s
+        self.samples = []
+        self.source = None
+        self._stop = threading.Event()
+        self._thread = None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        if cands:
+            self.source, self._path, self._read = "sysfs hwmon freq1_input", cands[0], self._read_hwmon
+        else:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            if cands:
+                self.source, self._path, self._read = "sysfs pp_dpm_sclk", cands[0], self._read_dpm
+            else:
+                import shutil
+                if shutil.which("rocm-smi"):
+                    self.source, self._path, self._read = "rocm-smi --showclocks", None, self._read_smi
+                    self.period = max(self.period, 0.25)
+
+    def _read_hwmon(self):
+        with open(self._path) as f:
+            return float(f.read().strip()) / 1e6
+
+    def _read_dpm(self):
+        with open(self._path) as f:
+            for line in f:
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        return None
+
+    def _read_smi(self):
+        import re
+        out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz", out)
+        return float(m.group(1)) if m else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.source:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread:
+            self._thread.join(timeout=10)
+
+    def summary(self):
+        if not self.samples:
+            return {"source": self.source, "samples": 0}
+        return {"source": self.source, "samples": len(self.samples), "median_MHz": round(_median(self.samples), 1),
+                "min_MHz": round(min(self.samples), 1), "max_MHz": round(max(self.samples), 1)}
+
+
+def sustained_leg(torch, pkg, step_fn, stream, kernel_ms_hint, seconds, algo_bytes):
+    """>= `seconds` of back-to-back launches of the workload (one event between consecutive launches, so a period
+    includes whatever gap the launches leave), with the shader clock measured underneath by a one-wave probe kernel
+    on a second stream (s_memtime / s_memrealtime) and the driver-reported sclk sampled from the host.  Reports the
+    median period of the first 20 launches, of every later 10 % slice and of the last 20 %."""
+    n = int(min(40000, max(200, math.ceil(seconds * 1e3 / max(kernel_ms_hint, 1e-3)))))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    probe_stream = torch.cuda.Stream()
+    est_ms = n * kernel_ms_hint
+    torch.cuda.synchronize()
+    time.sleep(0.5)  # start from an idle (cool, high-clock) chip, like a fresh caller would
+    probes = []
+    with SclkSampler() as sclk:
+        t0 = time.perf_counter()
+        # three probes: the first 10 % of the run, the middle, the last 30 %
+        try:
+            probes.append(("first_10pct", pkg.clock_probe(int(est_ms * 1e3 * 0.10), probe_stream)))
+        except Exception as e:
+            probes.append(("error", str(e)))
+        for i in range(n):
+            if i == n // 2 and probes and probes[0][0] != "error":
+                probes.append(("middle_10pct", pkg.clock_probe(int(est_ms * 1e3 * 0.10), probe_stream)))
+            if i == (n * 7) // 10 and probes and probes[0][0] != "error":
+                probes.append(("last_25pct", pkg.clock_probe(int(est_ms * 1e3 * 0.25), probe_stream)))
+            ev[i].record(stream)
+            step_fn(i)
+        ev[n].record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+    slices = []
+    for d in range(10):
+        lo, hi = (n * d) // 10, (n * (d + 1)) // 10
+        slices.append(round(_median(per[lo:hi]), 5))
+    last = per[(n * 8) // 10:]
+    last_ms = _median(last)
+    clock = {}
+    for name, res in probes:
+        if name == "error":
+            clock["probe_error"] = res
+            continue
+        r = res()
+        if r:
+            clock[name] = {"shader_MHz": round(r["shader_MHz"], 1), "interval_ms": round(r["interval_ms"], 2)}
+    clock["method"] = ("one sleeping wave on a second stream reads s_memtime (shader cycles) and s_memrealtime (constant "
+                       "%s kHz) at both ends of its interval while the launches run" % pkg.lib().icamd_wall_clock_rate_khz())
+    clock["driver_sclk"] = sclk.summary()
+    return {
+        "launches": n, "wall_s": round(wall, 3), "mean_ms_per_launch_wall": round(wall / n * 1e3, 5),
+        "median_ms_first_20": round(_median(per[:20]), 5), "median_ms_by_decile": slices,
+        "median_ms_last_20pct": round(last_ms, 5), "min_ms": round(min(per), 5), "max_ms": round(max(per), 5),
+        "achieved_GBps_last_20pct": round(algo_bytes / (last_ms * 1e-3) / 1e9, 1),
+        "frac_last_20pct": round(algo_bytes / (last_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "timing": "HIP events on the launch stream, one between consecutive launches (period = kernel + launch gap)",
+    }, clock
+
+
+def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, stream, bytes_per_px, calls=None):
+    """The literal shape of the BASELINE configuration and of Compressor::Compress (compressor.h:77-80): ONE texture
+    per call, rotating through the batch's distinct textures (>= 256 MiB of distinct sources, so every call reads HBM,
+    not the Infinity Cache), a HIP event pair around every call."""
+    per_image_out = pkg.encoded_size(codec, size, size)
+    out = torch.empty((batch, per_image_out), dtype=torch.uint8, device=src.device)
+    distinct_bytes = batch * size * size * comps
+    calls = calls or max(256, min(2000, 8 * batch * max(1, (256 << 20) // max(distinct_bytes, 1))))
+
+    def call(i):
+        k = i % batch
+        r = pkg.encode_device(codec, src[k], size, size, comps, etc_strategy=strategy, n_images=1, out=out[k:k + 1],
+                              stream=stream)
+        assert r is not None
+    for i in range(min(calls, 2 * batch)):
+        call(i)
+    torch.cuda.synchronize()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(calls)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(calls)]
+    t0 = time.perf_counter()
+    for i in range(calls):
+        starts[i].record(stream)
+        call(i)
+        ends[i].record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    med = _median(per)
+    algo = size * size * bytes_per_px
+    return {
+        "texture": [size, size], "distinct_textures_rotated": batch, "distinct_source_MiB": distinct_bytes >> 20,
+        "calls": calls, "median_ms_per_call": round(med, 5), "min_ms": round(min(per), 5), "max_ms": round(max(per), 5),
+        "back_to_back_ms_per_call_wall": round(wall / calls * 1e3, 5),
+        "value": round(size * size / (med * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+        "achieved_GBps": round(algo / (med * 1e-3) / 1e9, 1), "frac": round(algo / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "note": "one icamd_encode_device call = one config-sized image; HIP event pair per call on the launch stream",
+    }
 
 
 def main():
@@ -457,6 +634,27 @@ def main():
                 result["host_api"] = host_api_leg(pkg, T, codec, size, args.etc_strategy)
             except Exception as e:
                 result["host_api"] = "unavailable: %s" % e
+        if world == 1 and not args.no_sustained:
+            try:
+                sus, clock = sustained_leg(torch, pkg, lambda i: step(outs[0]), stream, kernel_ms, args.sustained_seconds,
+                                           algo_bytes)
+                result["sustained"] = sus
+                result["clock"] = clock
+                result["roofline"]["sustained_frac"] = sus["frac_last_20pct"]
+                result["roofline"]["sustained_kernel_ms"] = sus["median_ms_last_20pct"]
+                mhz = (clock.get("last_25pct") or {}).get("shader_MHz")
+                if mhz:
+                    result["roofline"]["effective_clock_MHz"] = mhz
+            except Exception as e:
+                result["sustained"] = "unavailable: %s: %s" % (type(e).__name__, e)
+        if world == 1 and not args.no_single_image:
+            try:
+                result["single_image"] = single_image_leg(torch, pkg, codec, comps, src, size, batch, args.etc_strategy,
+                                                          stream, bytes_per_px)
+            except Exception as e:
+                result["single_image"] = "unavailable: %s: %s" % (type(e).__name__, e)
+        result["library"] = {"path": os.path.relpath(pkg.LIB_PATH, ROOT), "overridden": bool(pkg.LIB_OVERRIDDEN),
+                             "version": pkg.lib().icamd_version().decode()}
         print(json.dumps(result))
     if distributed:
         dist.barrier()

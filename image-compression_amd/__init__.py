@@ -38,6 +38,8 @@ EXPORTS = [
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
     "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
     "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
+    "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
 ]
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -103,6 +105,21 @@ def lib():
             L.icamd_host_unregister.argtypes = [_vp]
             L.icamd_pvrtc2_decompress.restype = _ci
             L.icamd_pvrtc2_decompress.argtypes = [_u32, _vp, _sz, _vp, _sz]
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_create_solid_device"):  # r03 entry points
+            L.icamd_create_solid_device.restype = _ci
+            L.icamd_create_solid_device.argtypes = [_ci, _ci, _u32, _u32, _vp, _vp, _sz, _vp]
+            L.icamd_create_solid.restype = _ci
+            L.icamd_create_solid.argtypes = [_ci, _ci, _u32, _u32, _vp, _vp, _sz]
+            L.icamd_copy_subimage_device.restype = _ci
+            L.icamd_copy_subimage_device.argtypes = [_ci, _ci, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]
+            L.icamd_copy_subimage.restype = _ci
+            L.icamd_copy_subimage.argtypes = [_ci, _ci, _u32, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _sz]
+            L.icamd_encode_batch_sharded_device.restype = _ci
+            L.icamd_encode_batch_sharded_device.argtypes = [_ci, _ci, _ci, _ci, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _ci,
+                                                            _ci, _vp, _sz, _vp]
+            L.icamd_clock_probe_device.restype = _ci
+            L.icamd_clock_probe_device.argtypes = [_vp, _u32, _vp]
+            L.icamd_wall_clock_rate_khz.restype = _u32
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -332,3 +349,95 @@ def compress_batch_host(compressor, fmt, images, height, width, devices, *, padd
     if st < 0:
         _check(st, "icamd_compress_batch")
     return [outs[i][:size].tobytes() if statuses[i] == OK else None for i in range(n)]
+
+
+def create_solid_device(compressor, fmt, height, width, color, *, device=None, out=None, stream=None):
+    """Compressor::CreateSolidImage into a device-resident block grid; returns the uint8 device tensor, or None where
+    the reference returns false."""
+    c = bytes(bytearray(color))
+    buf = (ctypes.c_uint8 * max(len(c), 4))(*c)
+    n = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    if out is None:
+        out = torch.empty((max(n, 1),), dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+    st = lib().icamd_create_solid_device(compressor, fmt, height, width, buf, ctypes.c_void_p(out.data_ptr()), n,
+                                         _stream_handle(stream))
+    return out[:n] if _check(st, "icamd_create_solid_device") else None
+
+
+def create_solid_host(compressor, fmt, height, width, color):
+    import numpy as np
+    c = bytes(bytearray(color))
+    buf = (ctypes.c_uint8 * max(len(c), 4))(*c)
+    n = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = np.zeros(max(n, 1), np.uint8)
+    st = lib().icamd_create_solid(compressor, fmt, height, width, buf, out.ctypes.data, n)
+    return out[:n].tobytes() if _check(st, "icamd_create_solid") else None
+
+
+def copy_subimage_device(compressor, fmt, blocks, compressed_height, compressed_width, start_row, start_column, height,
+                         width, *, stream=None):
+    """Compressor::CopySubimage on a device-resident block grid (torch.uint8 CUDA tensor); device tensor or None."""
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+    n = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = torch.empty((max(n, 1),), dtype=torch.uint8, device=blocks.device)
+    st = lib().icamd_copy_subimage_device(compressor, fmt, compressed_height, compressed_width,
+                                          ctypes.c_void_p(blocks.data_ptr()), start_row, start_column, height, width,
+                                          ctypes.c_void_p(out.data_ptr()), n, _stream_handle(stream))
+    return out[:n] if _check(st, "icamd_copy_subimage_device") else None
+
+
+def copy_subimage_host(compressor, fmt, blocks, compressed_height, compressed_width, start_row, start_column, height,
+                       width):
+    import numpy as np
+    b = np.frombuffer(blocks, np.uint8)
+    n = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = np.zeros(max(n, 1), np.uint8)
+    st = lib().icamd_copy_subimage(compressor, fmt, compressed_height, compressed_width, b.ctypes.data, start_row,
+                                   start_column, height, width, out.ctypes.data, n)
+    return out[:n].tobytes() if _check(st, "icamd_copy_subimage") else None
+
+
+def encode_batch_sharded_device(codec, srcs, height, width, src_components, devices, *, swap_rb=False,
+                                etc_strategy=ETC_SMALLER_ERROR, row_stride_bytes=None, outs=None, gather_device=-1,
+                                gathered=None):
+    """icamd_encode_batch_sharded_device: `srcs` = list of torch.uint8 CUDA tensors, image i on device
+    devices[i % len(devices)]; `outs` = optional list of per-image output tensors (same devices); gather_device >= 0
+    additionally collects every image into `gathered` ([n, encoded_size] uint8 on that device, allocated if None).
+    Returns (statuses, outs, gathered); synchronous."""
+    n = len(srcs)
+    per = encoded_size(codec, height, width)
+    stride = width * src_components if row_stride_bytes is None else row_stride_bytes
+    for i, s in enumerate(srcs):
+        assert s.is_cuda and s.dtype == torch.uint8 and s.is_contiguous()
+        assert s.device.index == devices[i % len(devices)], "image %d is not on its listed device" % i
+    if gather_device >= 0 and gathered is None:
+        gathered = torch.empty((n, per), dtype=torch.uint8, device=torch.device("cuda", gather_device))
+    torch.cuda.synchronize()  # the sources were produced on torch streams; the library uses its own
+    in_ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    out_ptrs = None if outs is None else (ctypes.c_void_p * n)(*[(o.data_ptr() if o is not None else None) for o in outs])
+    devs = (ctypes.c_int * len(devices))(*devices)
+    statuses = (ctypes.c_int * n)()
+    st = lib().icamd_encode_batch_sharded_device(codec, etc_strategy, src_components, int(swap_rb), height, width, stride,
+                                                 n, in_ptrs, out_ptrs, devs, len(devices), gather_device,
+                                                 None if gathered is None else ctypes.c_void_p(gathered.data_ptr()),
+                                                 per if gathered is None else gathered.stride(0), statuses)
+    if st < 0:
+        _check(st, "icamd_encode_batch_sharded_device")
+    return list(statuses), outs, gathered
+
+
+def clock_probe(duration_us, stream):
+    """Enqueues the one-wave clock probe on `stream`; returns a callable that (after a synchronize) yields the mean
+    shader clock in MHz over the probe's interval, or None if the counters are unusable."""
+    out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    khz = lib().icamd_wall_clock_rate_khz()
+    st = lib().icamd_clock_probe_device(ctypes.c_void_p(out.data_ptr()), int(duration_us), _stream_handle(stream))
+    _check(st, "icamd_clock_probe_device")
+
+    def result():
+        cyc, ticks = [int(v) for v in out.cpu().tolist()]
+        if ticks <= 0 or khz == 0:
+            return None
+        return {"shader_MHz": cyc / ticks * khz / 1e3, "shader_cycles": cyc, "ref_ticks": ticks, "ref_clock_kHz": khz,
+                "interval_ms": ticks / khz}
+    return result

@@ -155,4 +155,74 @@ hipError_t launch_transcode_dxt1_to_etc1(void *blocks, uint32_t n_blocks, hipStr
   return hipGetLastError();
 }
 
+// ---- CreateSolidImage / CopySubimage on device-resident block grids (helper.h:522-592) ----
+
+// One block replicated n times: lane i of the grid-stride loop writes block i (8 or 16 bytes, streaming stores; the
+// pointer only needs the 4-byte alignment of the other block-domain operations).
+struct FillParams {
+  uint8_t *dst;
+  uint64_t n_blocks;
+  uint32_t w[4];
+  uint32_t words;  // 2 or 4
+};
+extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_fill_blocks_kernel(FillParams P) {
+  const uint64_t stride = (uint64_t)gridDim.x * kThreadsPerWorkgroup;
+  for (uint64_t k = (uint64_t)blockIdx.x * kThreadsPerWorkgroup + threadIdx.x; k < P.n_blocks; k += stride) {
+    if (P.words == 4) store_stream16(P.dst + k * 16u, P.w[0], P.w[1], P.w[2], P.w[3]);
+    else store_stream8(P.dst + k * 8u, P.w[0], P.w[1]);
+  }
+}
+
+// Sub-rectangle of a block grid: output block (r, c) = source block (r0 + r, c0 + c); grid = (column chunks, rows),
+// consecutive lanes = consecutive blocks of one row (coalesced on both sides).
+struct SubimageParams {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint32_t src_cols, r0, c0, rows, cols, words, row_first;
+};
+extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_copy_subimage_kernel(SubimageParams P) {
+  const uint32_t c = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x, r = P.row_first + blockIdx.y;
+  if (c >= P.cols) return;
+  const size_t so = ((size_t)(P.r0 + r) * P.src_cols + P.c0 + c) * (P.words * 4u), dof = ((size_t)r * P.cols + c) * (P.words * 4u);
+  if (P.words == 4) {
+    const U4 v = *reinterpret_cast<const U4 *>(P.src + so);
+    store_stream16(P.dst + dof, v.x, v.y, v.z, v.w);
+  } else {
+    const U2 v = *reinterpret_cast<const U2 *>(P.src + so);
+    store_stream8(P.dst + dof, v.x, v.y);
+  }
+}
+
+hipError_t launch_fill_blocks(void *dst, uint64_t n_blocks, int block_bytes, const uint32_t words[4], hipStream_t stream) {
+  if (n_blocks == 0) return hipSuccess;
+  FillParams P;
+  P.dst = static_cast<uint8_t *>(dst);
+  P.n_blocks = n_blocks;
+  P.words = (uint32_t)block_bytes / 4u;
+  for (int i = 0; i < 4; ++i) P.w[i] = words[i];
+  uint64_t wgs = (n_blocks + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup;
+  if (wgs > 256u * 64u) wgs = 256u * 64u;  // 8 waves on every SIMD several times over; the loop covers the rest
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(icamd_fill_blocks_kernel, dim3((uint32_t)wgs), dim3(kThreadsPerWorkgroup), 0, stream, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_copy_subimage(int block_bytes, const void *src, uint32_t src_cols, uint32_t r0, uint32_t c0,
+                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream) {
+  if (rows == 0 || cols == 0) return hipSuccess;
+  SubimageParams P;
+  P.src = static_cast<const uint8_t *>(src);
+  P.dst = static_cast<uint8_t *>(dst);
+  P.src_cols = src_cols; P.r0 = r0; P.c0 = c0; P.rows = rows; P.cols = cols;
+  P.words = (uint32_t)block_bytes / 4u;
+  (void)hipGetLastError();
+  const uint32_t gx = (cols + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup;
+  for (uint32_t first = 0; first < rows; first += 65535u) {
+    P.row_first = first;
+    hipLaunchKernelGGL(icamd_copy_subimage_kernel, dim3(gx, rows - first < 65535u ? rows - first : 65535u),
+                       dim3(kThreadsPerWorkgroup), 0, stream, P);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace icamd

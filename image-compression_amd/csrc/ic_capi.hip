@@ -773,5 +773,212 @@ int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t 
   return first;
 }
 
+// ---- CreateSolidImage / CopySubimage
+
+namespace {
+// Quantize8<n> (color_util.h:156-164)
+uint32_t quantize8(uint32_t v, uint32_t bits) {
+  const uint32_t i = v * ((1u << bits) - 1u) + 128u;
+  return (i + (i >> 8)) >> 8;
+}
+// The one block CreateSolidImage replicates, as little-endian dwords; returns its size in bytes, 0 where the reference
+// returns false.  DXT (dxtc_compressor.cc:42-49,77-82,820-839): c0 = c1 = RGB565(color) -- no red/blue swap --, index
+// bits zero; DXT5 puts alpha0 = alpha1 = color[3] and zero codes in front.  ETC (etc_compressor.cc:595-617,802-812):
+// differential mode, 5-bit base = color >> 3 (the "adjusted" colour computed there is never used), zero difference,
+// codeword 0 twice, all indices 0; big-endian high word, then the zero low word.
+uint32_t solid_block(int compressor, int format, const uint8_t *color, uint32_t w[4]) {
+  w[0] = w[1] = w[2] = w[3] = 0;
+  const int comps = format_components(format);
+  if (comps == 0 || !color) return 0;
+  if (compressor == ICAMD_COMPRESSOR_ETC) {
+    if (format != ICAMD_RGB) return 0;
+    const uint32_t hi = 2u | (uint32_t)(color[0] >> 3) << 27 | (uint32_t)(color[1] >> 3) << 19 | (uint32_t)(color[2] >> 3) << 11;
+    w[0] = __builtin_bswap32(hi);
+    return 8;
+  }
+  if (compressor != ICAMD_COMPRESSOR_DXTC) return 0;  // pvrtc_compressor.cc:693-698
+  const uint32_t c565 = quantize8(color[0], 5) << 11 | quantize8(color[1], 6) << 5 | quantize8(color[2], 5);
+  if (comps == 3) {
+    w[0] = c565 | c565 << 16;
+    return 8;
+  }
+  w[0] = (uint32_t)color[3] | (uint32_t)color[3] << 8;
+  w[2] = c565 | c565 << 16;
+  return 16;
+}
+// CopySubimage's argument check (helper.h:555-563) and geometry
+bool subimage_geometry(int compressor, int format, uint32_t ch, uint32_t cw, uint32_t row, uint32_t col, uint32_t h,
+                       uint32_t w, int *block_bytes) {
+  int codec;
+  if (!blockop_codec(compressor, format, &codec)) return false;
+  *block_bytes = codec == ICAMD_DXT5 ? 16 : 8;
+  if (row % 4 || col % 4 || h % 4 || w % 4) return false;
+  // 64-bit sums: the reference's uint32 start + extent can wrap and then accept a window outside the image
+  return !(row > ch || col > cw || (uint64_t)row + h > ch || (uint64_t)col + w > cw);
+}
+}  // namespace
+
+int icamd_create_solid_device(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color,
+                              void *d_out, size_t out_size, void *hip_stream) {
+  uint32_t w[4];
+  const uint32_t bb = solid_block(compressor, format, color, w);
+  if (bb == 0 || !d_out) return ICAMD_FALSE;
+  const uint64_t n = (uint64_t)num_blocks4(height) * num_blocks4(width);
+  if (out_size != n * bb) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
+  if (reinterpret_cast<uintptr_t>(d_out) % 4u) return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  ICAMD_HIP(icamd::launch_fill_blocks(d_out, n, (int)bb, w, static_cast<hipStream_t>(hip_stream)), "launch fill");
+  return ICAMD_OK;
+}
+
+// Host buffers in, host buffers out: replicating one block is byte shuffling with nothing to offload (a PCIe round
+// trip would be pure overhead), exactly what the reference does (helper.h:536-540).
+int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color, uint8_t *out,
+                       size_t out_size) {
+  uint32_t w[4];
+  const uint32_t bb = solid_block(compressor, format, color, w);
+  if (bb == 0 || !out) return ICAMD_FALSE;
+  const uint64_t n = (uint64_t)num_blocks4(height) * num_blocks4(width);
+  if (out_size != n * bb) return ICAMD_FALSE;
+  for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * bb, w, bb);
+  return ICAMD_OK;
+}
+
+int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                               const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
+                               uint32_t width, void *d_out, size_t out_size, void *hip_stream) {
+  int bb;
+  if (!d_blocks || !d_out ||
+      !subimage_geometry(compressor, format, compressed_height, compressed_width, start_row, start_column, height, width, &bb))
+    return ICAMD_FALSE;
+  const uint32_t rows = num_blocks4(height), cols = num_blocks4(width);
+  if (out_size != (size_t)rows * cols * (size_t)bb) return ICAMD_FALSE;
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  ICAMD_HIP(icamd::launch_copy_subimage(bb, d_blocks, num_blocks4(compressed_width), start_row / 4u, start_column / 4u,
+                                        rows, cols, d_out, static_cast<hipStream_t>(hip_stream)), "launch copy_subimage");
+  return ICAMD_OK;
+}
+
+// Host form: block-row memcpys like the reference (helper.h:583-589); nothing to offload.
+int icamd_copy_subimage(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                        const uint8_t *blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
+                        uint32_t width, uint8_t *out, size_t out_size) {
+  int bb;
+  if (!blocks || !out ||
+      !subimage_geometry(compressor, format, compressed_height, compressed_width, start_row, start_column, height, width, &bb))
+    return ICAMD_FALSE;
+  const uint32_t rows = num_blocks4(height), cols = num_blocks4(width), src_cols = num_blocks4(compressed_width);
+  if (out_size != (size_t)rows * cols * (size_t)bb) return ICAMD_FALSE;
+  const uint8_t *src = blocks + ((size_t)(start_row / 4u) * src_cols + start_column / 4u) * (size_t)bb;
+  for (uint32_t r = 0; r < rows; ++r)
+    std::memcpy(out + (size_t)r * cols * bb, src + (size_t)r * src_cols * bb, (size_t)cols * bb);
+  return ICAMD_OK;
+}
+
+// ---- diagnostics
+
+uint32_t icamd_wall_clock_rate_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 0;
+  return (uint32_t)khz;
+}
+
+int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stream) {
+  if (!d_out16 || reinterpret_cast<uintptr_t>(d_out16) % 8u) return fail(ICAMD_ERR_ARG, "clock probe: 8-byte aligned 16-byte buffer needed");
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  const uint32_t khz = icamd_wall_clock_rate_khz();
+  if (khz == 0) return fail(ICAMD_ERR_HIP, "hipDeviceAttributeWallClockRate unavailable");
+  const uint64_t ticks = (uint64_t)duration_us * khz / 1000u;
+  ICAMD_HIP(icamd::launch_clock_probe(static_cast<uint64_t *>(d_out16), ticks, static_cast<hipStream_t>(hip_stream)), "launch clock probe");
+  return ICAMD_OK;
+}
+
+// ---- multi-GPU from one process, device-resident
+
+int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_components, int swap_rb, uint32_t height,
+                                      uint32_t width, uint32_t row_stride_bytes, uint32_t n_images,
+                                      const void *const *d_srcs, void *const *d_dsts, const int *devices, int n_devices,
+                                      int gather_device, void *d_gathered, size_t gathered_image_stride_bytes,
+                                      int *statuses) {
+  if (n_images == 0) return ICAMD_OK;
+  if (!d_srcs || !devices || n_devices <= 0) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: null list");
+  const bool gather = gather_device >= 0;
+  if (!gather && !d_dsts) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: no output (d_dsts and no gather)");
+  if (gather && !d_gathered) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: gather without a buffer");
+  if (height == 0 || width == 0) return ICAMD_FALSE;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  int visible = 0;
+  ICAMD_HIP(hipGetDeviceCount(&visible), "hipGetDeviceCount");
+  for (int d = 0; d < n_devices; ++d)
+    if (devices[d] < 0 || devices[d] >= visible) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: bad device ordinal");
+  if (gather && gather_device >= visible) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: bad gather device");
+  const size_t out_size = icamd_encoded_size(codec, height, width);
+  if (gather && gathered_image_stride_bytes < out_size) return fail(ICAMD_ERR_ARG, "gathered image stride smaller than an image");
+  int prev_device = 0;
+  (void)hipGetDevice(&prev_device);
+  std::vector<int> local(n_images, ICAMD_OK);
+  std::vector<std::string> errors((size_t)n_devices);
+  std::vector<std::thread> workers;
+  workers.reserve((size_t)n_devices);
+  for (int d = 0; d < n_devices; ++d) {
+    workers.emplace_back([&, d]() {
+      const int dev = devices[d];
+      auto fail_all = [&](int code, const char *what) {
+        for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) local[i] = code;
+        errors[(size_t)d] = what;
+      };
+      if (hipSetDevice(dev) != hipSuccess) return fail_all(ICAMD_ERR_HIP, "hipSetDevice failed");
+      std::unique_ptr<Staging> st = pool_take(dev);
+      // images without an output buffer of their own (gather only) are encoded into one of two scratch buffers, so
+      // that the peer copy of image j overlaps the encode of image j + 1 (two streams, alternating)
+      bool need_scratch = false;
+      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices)
+        if (gather && (!d_dsts || !d_dsts[i]) && dev != gather_device) need_scratch = true;
+      if (st->ensure(need_scratch ? out_size : 1, need_scratch ? out_size : 1) != ICAMD_OK) {
+        pool_give(std::move(st));
+        return fail_all(ICAMD_ERR_ALLOC, "staging allocation failed");
+      }
+      uint32_t j = 0;
+      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices, ++j) {
+        hipStream_t s = (j & 1u) ? st->stream2 : st->stream;
+        uint8_t *slot = gather ? static_cast<uint8_t *>(d_gathered) + (size_t)i * gathered_image_stride_bytes : nullptr;
+        void *own = d_dsts ? d_dsts[i] : nullptr;
+        void *target = own ? own : (dev == gather_device ? static_cast<void *>(slot) : ((j & 1u) ? st->d_in : st->d_out));
+        if (!d_srcs[i]) { local[i] = ICAMD_FALSE; continue; }
+        local[i] = icamd_encode_device(codec, etc_strategy, src_components, swap_rb, height, width, height, width,
+                                       row_stride_bytes, 1, 0, 0, d_srcs[i], target, s);
+        if (local[i] == ICAMD_OK && gather && target != slot) {
+          // the encoded image travels device -> device (xGMI between GPUs); no host staging
+          const hipError_t e = dev == gather_device ? hipMemcpyAsync(slot, target, out_size, hipMemcpyDeviceToDevice, s)
+                                                    : hipMemcpyPeerAsync(slot, gather_device, target, dev, out_size, s);
+          if (e != hipSuccess) local[i] = fail(ICAMD_ERR_HIP, "gather copy", e);
+        }
+        if (local[i] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
+      }
+      const hipError_t e1 = hipStreamSynchronize(st->stream), e2 = hipStreamSynchronize(st->stream2);
+      if (e1 != hipSuccess || e2 != hipSuccess) fail_all(ICAMD_ERR_HIP, "stream synchronize failed");
+      pool_give(std::move(st));
+    });
+  }
+  for (std::thread &t : workers) t.join();
+  (void)hipSetDevice(prev_device);
+  int first = ICAMD_OK;
+  for (uint32_t i = 0; i < n_images; ++i) {
+    if (statuses) statuses[i] = local[i];
+    if (first == ICAMD_OK && local[i] != ICAMD_OK) first = local[i];
+  }
+  if (first < 0)
+    for (const std::string &e : errors)
+      if (!e.empty()) { g_last_error = e; break; }
+  return first;
+}
+
 #pragma GCC visibility pop
 }  // extern "C"

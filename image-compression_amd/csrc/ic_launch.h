@@ -101,6 +101,14 @@ struct BlockOpParams {
 hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream);
 hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream);
 hipError_t launch_transcode_dxt1_to_etc1(void *blocks, uint32_t n_blocks, hipStream_t stream);
+// CreateSolidImage: `words` (block_bytes / 4 of them) replicated n_blocks times.  CopySubimage: rows x cols blocks
+// starting at block (r0, c0) of a grid src_cols blocks wide.
+hipError_t launch_fill_blocks(void *dst, uint64_t n_blocks, int block_bytes, const uint32_t words[4], hipStream_t stream);
+hipError_t launch_copy_subimage(int block_bytes, const void *src, uint32_t src_cols, uint32_t r0, uint32_t c0,
+                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream);
+// Diagnostics: one wave spins for `ticks` periods of the constant-rate clock (s_memrealtime) and records how many shader
+// cycles (s_memtime) passed meanwhile: d_out[0] = shader cycles, d_out[1] = constant-rate ticks.
+hipError_t launch_clock_probe(uint64_t *d_out, uint64_t ticks, hipStream_t stream);
 
 const char *dxt_kernel_name(int codec, int comps);
 const char *etc1_kernel_name(int comps);

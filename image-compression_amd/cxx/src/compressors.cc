@@ -116,39 +116,34 @@ bool Downsample4x4(const CompressedImage &image, int compressor, int etc_strateg
                       "icamd_downsample");
 }
 
-// Compressor4x4Helper::CreateSolidImage (compressor4x4_helper.h:522-543): one block, replicated.  Pure byte
-// shuffling on the host -- there is no per-pixel work to offload.
-bool Solid4x4(const char *name, CompressedImage::Format format, uint32 height, uint32 width, const uint8 *block,
-              size_t block_size, CompressedImage *image) {
-  const size_t count = (size_t)BlocksFor(height) * BlocksFor(width);
+// Compressor4x4Helper::CreateSolidImage (compressor4x4_helper.h:522-543): image set-up here, the block and its
+// replication behind the C ABI (icamd_create_solid; device-resident grids: icamd_create_solid_device).
+bool Solid4x4(int compressor, const char *name, CompressedImage::Format format, uint32 height, uint32 width,
+              const uint8 *color, CompressedImage *image) {
+  const size_t block_size = (compressor == ICAMD_COMPRESSOR_ETC || GetNumFormatComponents(format) == 3) ? 8 : 16;
+  const size_t data_size = (size_t)BlocksFor(height) * BlocksFor(width) * block_size;
   const CompressedImage::Metadata metadata(format, name, height, width, 4 * BlocksFor(height), 4 * BlocksFor(width), 0);
-  if (!PrepareImage(metadata, count * block_size, image)) return false;
-  for (size_t i = 0; i < count; ++i) std::memcpy(image->GetMutableData() + i * block_size, block, block_size);
-  return true;
+  if (!PrepareImage(metadata, data_size, image)) return false;
+  return ReportStatus(icamd_create_solid(compressor, format, height, width, color, image->GetMutableData(), data_size),
+                      "icamd_create_solid");
 }
 
-// Compressor4x4Helper::CopySubimage (compressor4x4_helper.h:545-592): block-row memcpys.
-bool Subimage4x4(const CompressedImage &image, size_t block_size, uint32 start_row, uint32 start_column, uint32 height,
-                 uint32 width, CompressedImage *subimage) {
+// Compressor4x4Helper::CopySubimage (compressor4x4_helper.h:545-592): validation + set-up here (the reference refuses
+// BEFORE touching the output image), block-row copies behind the C ABI (icamd_copy_subimage / _device).
+bool Subimage4x4(const CompressedImage &image, int compressor, size_t block_size, uint32 start_row, uint32 start_column,
+                 uint32 height, uint32 width, CompressedImage *subimage) {
   const CompressedImage::Metadata &m = image.GetMetadata();
   if (start_row % 4 != 0 || start_column % 4 != 0 || height % 4 != 0 || width % 4 != 0 ||
       start_row > m.compressed_height || start_column > m.compressed_width ||
       start_row + height > m.compressed_height || start_column + width > m.compressed_width)
     return false;
-  const uint32 sub_rows = BlocksFor(height), sub_cols = BlocksFor(width), src_cols = BlocksFor(m.compressed_width);
+  const uint32 sub_rows = BlocksFor(height), sub_cols = BlocksFor(width);
+  const size_t data_size = (size_t)sub_rows * sub_cols * block_size;
   const CompressedImage::Metadata metadata(m.format, m.compressor_name, height, width, 4 * sub_rows, 4 * sub_cols, 0);
-  if (!PrepareImage(metadata, (size_t)sub_rows * sub_cols * block_size, subimage)) return false;
-  const uint8 *src = image.GetData() + ((size_t)(start_row / 4) * src_cols + start_column / 4) * block_size;
-  uint8 *dst = subimage->GetMutableData();
-  for (uint32 r = 0; r < sub_rows; ++r)
-    std::memcpy(dst + (size_t)r * sub_cols * block_size, src + (size_t)r * src_cols * block_size, sub_cols * block_size);
-  return true;
-}
-
-// Quantize8<n> (color_util.h:156-164)
-uint32 Quantize(uint32 v, uint32 bits) {
-  const uint32 i = v * ((1u << bits) - 1u) + 128u;
-  return (i + (i >> 8)) >> 8;
+  if (!PrepareImage(metadata, data_size, subimage)) return false;
+  return ReportStatus(icamd_copy_subimage(compressor, m.format, m.compressed_height, m.compressed_width, image.GetData(),
+                                          start_row, start_column, height, width, subimage->GetMutableData(), data_size),
+                      "icamd_copy_subimage");
 }
 
 }  // namespace
@@ -204,27 +199,15 @@ bool DxtcCompressor::Pad(const CompressedImage &image, uint32 padded_height, uin
 bool DxtcCompressor::CreateSolidImage(CompressedImage::Format format, uint32 height, uint32 width, const uint8 *color,
                                       CompressedImage *image) {
   if (!image) return false;
-  // dxtc_compressor.cc:42-49,77-82,820-839: c0 = c1 = RGB565(color) (no red/blue swap), index bits zero;
-  // DXT5 adds alpha0 = alpha1 = color[3] with zero codes in front.
-  const uint32 c565 = Quantize(color[0], 5) << 11 | Quantize(color[1], 6) << 5 | Quantize(color[2], 5);
-  uint8 block[16] = { 0 };
-  uint8 *c = block;
-  size_t size = 8;
-  if (GetNumFormatComponents(format) != 3) {
-    block[0] = block[1] = color[3];
-    c = block + 8;
-    size = 16;
-  }
-  c[0] = c[2] = (uint8)(c565 & 0xff);
-  c[1] = c[3] = (uint8)(c565 >> 8);
-  return Solid4x4("dxtc", format, height, width, block, size, image);
+  // dxtc_compressor.cc:820-839; the solid block itself: icamd_create_solid (ic_capi.hip, solid_block)
+  return Solid4x4(ICAMD_COMPRESSOR_DXTC, "dxtc", format, height, width, color, image);
 }
 
 bool DxtcCompressor::CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,
                                   uint32 width, CompressedImage *subimage) {
   if (!IsValidCompressedImage(image) || !subimage) return false;
-  return Subimage4x4(image, GetNumFormatComponents(image.GetMetadata().format) == 3 ? 8 : 16, start_row, start_column,
-                     height, width, subimage);
+  return Subimage4x4(image, ICAMD_COMPRESSOR_DXTC, GetNumFormatComponents(image.GetMetadata().format) == 3 ? 8 : 16,
+                     start_row, start_column, height, width, subimage);
 }
 
 // ------------------------------------------------------------------- ETC
@@ -277,18 +260,14 @@ bool EtcCompressor::Pad(const CompressedImage &image, uint32 padded_height, uint
 
 bool EtcCompressor::CreateSolidImage(CompressedImage::Format format, uint32 height, uint32 width, const uint8 *color,
                                      CompressedImage *image) {
-  if (!image || format != CompressedImage::kRGB) return false;
-  // CreateSolidBlock (etc_compressor.cc:595-617): differential mode, 5-bit base = color >> 3, zero difference,
-  // codeword 0 twice, all indices 0; stored as big-endian high word, then the (zero) low word.
-  const uint32 hi = 2u | (uint32)(color[0] >> 3) << 27 | (uint32)(color[1] >> 3) << 19 | (uint32)(color[2] >> 3) << 11;
-  const uint8 block[8] = { (uint8)(hi >> 24), (uint8)(hi >> 16), (uint8)(hi >> 8), (uint8)hi, 0, 0, 0, 0 };
-  return Solid4x4("etc", format, height, width, block, 8, image);
+  if (!image || format != CompressedImage::kRGB) return false;  // etc_compressor.cc:802-812
+  return Solid4x4(ICAMD_COMPRESSOR_ETC, "etc", format, height, width, color, image);
 }
 
 bool EtcCompressor::CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,
                                  uint32 width, CompressedImage *subimage) {
   if (!IsValidCompressedImage(image) || !subimage) return false;
-  return Subimage4x4(image, 8, start_row, start_column, height, width, subimage);
+  return Subimage4x4(image, ICAMD_COMPRESSOR_ETC, 8, start_row, start_column, height, width, subimage);
 }
 
 // ----------------------------------------------------------------- PVRTC

@@ -186,6 +186,28 @@ int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32
 int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
                      uint32_t uncompressed_width, const uint8_t *blocks, uint8_t *out, size_t out_size);
 
+/* Compressor::CreateSolidImage (compressor.h:124-127; helper.h:522-543; solid blocks dxtc_compressor.cc:42-49,77-82,
+ * 820-839, etc_compressor.cc:595-617,802-812): the block grid of a height x width image of one colour.  `color` is a
+ * HOST pointer to 3 (kRGB/kBGR) or 4 (kRGBA/kBGRA) bytes; out_size must be blocks * block size.  ICAMD_FALSE for PVRTC
+ * (pvrtc_compressor.cc:693-698), for ETC formats other than kRGB, and on a size mismatch.  The _device form fills a
+ * device-resident grid (one kernel, streaming stores); the host form replicates the block on the host like the reference
+ * (byte shuffling: nothing to offload). */
+int icamd_create_solid_device(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color,
+                              void *d_out, size_t out_size, void *hip_stream);
+int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color, uint8_t *out,
+                       size_t out_size);
+
+/* Compressor::CopySubimage (compressor.h:133-136; helper.h:545-592): the blocks of the height x width window at
+ * (start_row, start_column) of an image whose grid covers (compressed_height, compressed_width) pixels.  ICAMD_FALSE
+ * unless all four are multiples of 4 and the window lies inside the compressed image (helper.h:555-563), for PVRTC, and
+ * on a size mismatch. */
+int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                               const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
+                               uint32_t width, void *d_out, size_t out_size, void *hip_stream);
+int icamd_copy_subimage(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                        const uint8_t *blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
+                        uint32_t width, uint8_t *out, size_t out_size);
+
 /* TranscodeDxt1ToEtc1 (public/dxtc_to_etc_transcoder.h:24; dxtc_to_etc_transcoder.cc:29-40): in place. */
 int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream);
 int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes);
@@ -201,12 +223,36 @@ int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t 
                          uint32_t padding_bytes_per_row, uint32_t n_images, const uint8_t *const *buffers,
                          uint8_t *const *outs, size_t out_size, const int *devices, int n_devices, int *statuses);
 
+/* The same for images that are ALREADY RESIDENT IN HBM: image i lives on device
+ * devices[i % n_devices] (d_srcs[i] is a pointer on that device) and is encoded there exactly like
+ * icamd_encode_device(codec, ..., height, width, height, width, row_stride_bytes, 1 image) -- Compressor::Compress
+ * (compressor.h:77-80) per image, no pixel ever crosses PCIe.  One host worker thread per list entry drives two HIP
+ * streams on its device.  Output:
+ *   d_dsts[i] != NULL      the image's blocks are written there (a pointer on the image's own device);
+ *   gather_device >= 0     every image's blocks additionally land at d_gathered + i * gathered_image_stride_bytes, a
+ *                          buffer on gather_device ("rank 0"): device-to-device copies (hipMemcpyPeerAsync, xGMI between
+ *                          GPUs) that overlap the next image's encode; images on gather_device itself are encoded
+ *                          straight into their slot when they have no d_dsts entry.  d_dsts may be NULL altogether.
+ * Returns after all streams have drained.  statuses / return value as icamd_compress_batch. */
+int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_components, int swap_rb, uint32_t height,
+                                      uint32_t width, uint32_t row_stride_bytes, uint32_t n_images,
+                                      const void *const *d_srcs, void *const *d_dsts, const int *devices, int n_devices,
+                                      int gather_device, void *d_gathered, size_t gathered_image_stride_bytes,
+                                      int *statuses);
+
 /* ---- runtime ---- */
 int icamd_device_count(void);             /* HIP devices visible; 0 if none */
 const char *icamd_last_error(void);       /* thread-local message for the last negative status */
 const char *icamd_version(void);
 /* Name of the __global__ kernel a given configuration launches (for matching rocprofv3 rows). */
 const char *icamd_kernel_name(int codec, int src_components);
+
+/* ---- diagnostics (measurement aid; not part of the encode path) ----
+ * Effective shader clock under load: enqueues ONE wave on hip_stream that sleeps for duration_us and then writes
+ * {shader cycles elapsed (s_memtime), constant-rate ticks elapsed (s_memrealtime)} as two uint64 to d_out16.  Run it
+ * on a stream of its own next to the kernels being timed; mean clock = cycles / ticks * icamd_wall_clock_rate_khz(). */
+int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stream);
+uint32_t icamd_wall_clock_rate_khz(void);  /* hipDeviceAttributeWallClockRate of the current device; 0 if unknown */
 
 #ifdef __cplusplus
 }

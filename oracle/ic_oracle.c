@@ -858,6 +858,7 @@ int ico_create_solid(int compressor, int format, uint32_t h, uint32_t w, const u
 int ico_copy_subimage(int compressor, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks, uint32_t row,
                       uint32_t col, uint32_t h, uint32_t w, uint8_t *out) {
   if (compressor == ICO_COMPRESSOR_PVRTC) return 0;
+  if (compressor == ICO_COMPRESSOR_ETC && format != ICO_RGB) return 0;     /* etc.cc:719-722 (IsValidCompressedImage) */
   if (row % 4 || col % 4 || h % 4 || w % 4 || row > ch || col > cw || row + h > ch || col + w > cw) return 0;
   size_t bb = block_bytes(block_codec(compressor, format));
   uint32_t ocols = nblk(cw), scols = nblk(w), srows = nblk(h);

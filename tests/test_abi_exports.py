@@ -81,3 +81,31 @@ int main(void) {
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=120, check=True).stdout.decode().split()
     assert out[:4] == [str(T.oracle_size(T.DXTC, T.RGB, 61, 59)), "1", "1", str(64 * 64 // 4)]
+
+
+def test_host_forms_of_create_solid_and_copy_subimage_match_oracle_and_reference(pkg):
+    """icamd_create_solid / icamd_copy_subimage (host buffers; byte shuffling, no device needed -- the reference's
+    helper.h:522-592) against the oracle and, where it was built, the compiled reference."""
+    import numpy as np
+    import ic_testlib as T
+    rng = np.random.default_rng(7)
+    for compressor in (T.DXTC, T.ETC, T.PVRTC):
+        for fmt in (T.RGB, T.BGR, T.RGBA, T.BGRA):
+            for (h, w) in ((4, 4), (1, 1), (9, 5), (64, 20), (0, 8)):
+                color = [int(v) for v in rng.integers(0, 256, 4)]
+                got = pkg.create_solid_host(compressor, fmt, h, w, color)
+                assert got == T.oracle_create_solid(compressor, fmt, h, w, color), (compressor, fmt, h, w)
+                if T.have_ref() and h and w:
+                    assert got == T.ref_create_solid(compressor, fmt, h, w, color), (compressor, fmt, h, w)
+    for compressor, fmt in ((T.DXTC, T.RGB), (T.DXTC, T.RGBA), (T.ETC, T.RGB), (T.ETC, T.RGBA), (T.PVRTC, T.RGBA)):
+        h, w = 21, 30
+        ch, cw = 24, 32
+        bb = 8 if (compressor == T.ETC or T.comps_of(fmt) == 3) else 16
+        blocks = rng.integers(0, 256, (ch // 4) * (cw // 4) * bb, dtype=np.uint8).tobytes()
+        for (r, c, sh, sw) in ((0, 0, 24, 32), (4, 8, 8, 12), (20, 28, 4, 4), (8, 0, 0, 32), (0, 0, 28, 32), (4, 4, 21, 8),
+                               (2, 0, 4, 4), (24, 32, 0, 0), (0, 28, 4, 8), (4, 4, 0xfffffffc, 4)):
+            got = pkg.copy_subimage_host(compressor, fmt, blocks, ch, cw, r, c, sh, sw)
+            if sh < 1 << 20:
+                assert got == T.oracle_copy_subimage(compressor, fmt, blocks, ch, cw, r, c, sh, sw), (compressor, fmt, r, c, sh, sw)
+            else:
+                assert got is None  # start + extent wraps 32 bits: refused here (the reference would read out of bounds)

@@ -751,3 +751,142 @@ def test_host_api_band_pipeline(pkg):
         pkg.host_unregister(img)
     # a wrong out_size is refused before anything is staged (and a huge one allocates nothing)
     assert pkg.compress_host(T.DXTC, T.RGB, img, h, w, out_size=8) is None
+
+
+# ---- SURVEY 8f row 2 on device: CreateSolidImage / CopySubimage on device-resident block grids
+
+def test_create_solid_and_copy_subimage_on_device_match_oracle(pkg):
+    import torch
+    rng = np.random.default_rng(11)
+    for compressor in (T.DXTC, T.ETC, T.PVRTC):
+        for fmt in (T.RGB, T.BGR, T.RGBA, T.BGRA):
+            for (h, w) in ((4, 4), (1, 1), (9, 5), (257, 1023), (2048, 2048)):
+                color = [int(v) for v in rng.integers(0, 256, 4)]
+                want = T.oracle_create_solid(compressor, fmt, h, w, color)
+                got = pkg.create_solid_device(compressor, fmt, h, w, color)
+                assert (None if got is None else _host(got)) == want, (compressor, fmt, h, w)
+    # a wrong output size is the reference's external-storage mismatch
+    out = torch.empty(100, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().icamd_create_solid_device(T.DXTC, T.RGB, 8, 8, (pkg.ctypes.c_uint8 * 4)(1, 2, 3, 4),
+                                               pkg.ctypes.c_void_p(out.data_ptr()), 100, None) == pkg.FALSE
+    for compressor, fmt in ((T.DXTC, T.RGB), (T.DXTC, T.BGRA), (T.ETC, T.RGB), (T.ETC, T.RGBA), (T.PVRTC, T.RGBA)):
+        ch, cw = 1024, 2052
+        bb = 8 if (compressor == T.ETC or T.comps_of(fmt) == 3) else 16
+        blocks = rng.integers(0, 256, (ch // 4) * (cw // 4) * bb, dtype=np.uint8)
+        d_blocks = _dev(blocks)
+        for (r, c, sh, sw) in ((0, 0, ch, cw), (4, 8, 8, 12), (ch - 4, cw - 4, 4, 4), (8, 0, 0, cw), (0, 0, ch + 4, cw),
+                               (512, 1024, 512, 1028), (2, 0, 4, 4), (ch, cw, 0, 0), (0, 4, 1024, 2048), (4, 4, 21, 8)):
+            want = T.oracle_copy_subimage(compressor, fmt, blocks.tobytes(), ch, cw, r, c, sh, sw)
+            got = pkg.copy_subimage_device(compressor, fmt, d_blocks, ch, cw, r, c, sh, sw)
+            assert (None if got is None else _host(got)) == want, (compressor, fmt, r, c, sh, sw)
+
+
+# ---- device-resident images on a device list, optional gather into one device's buffer
+
+def _sharded_case(pkg, codec, comps, size, n, devices, strategy=2):
+    import torch
+    imgs = [T.s_mixed(size, size, comps, index=40 + i) for i in range(n)]
+    srcs = [torch.from_numpy(im).to("cuda:%d" % devices[i % len(devices)]) for i, im in enumerate(imgs)]
+    want = [T.oracle_encode(codec, im, size, size, comps, 0, strategy) for im in imgs]
+    per = pkg.encoded_size(codec, size, size)
+    # (a) per-image outputs only
+    outs = [torch.zeros(per, dtype=torch.uint8, device=s.device) for s in srcs]
+    st, outs, _ = pkg.encode_batch_sharded_device(codec, srcs, size, size, comps, devices, etc_strategy=strategy, outs=outs)
+    assert st == [0] * n
+    for i in range(n):
+        assert outs[i].cpu().numpy().tobytes() == want[i], ("outs", codec, i)
+    # (b) gather only (no per-image buffers): scratch + device-to-device copies into the root buffer
+    for root in sorted(set(devices)):
+        st, _, gathered = pkg.encode_batch_sharded_device(codec, srcs, size, size, comps, devices, etc_strategy=strategy,
+                                                          gather_device=root)
+        assert st == [0] * n and gathered.device.index == root
+        g = gathered.cpu().numpy()
+        for i in range(n):
+            assert g[i].tobytes() == want[i], ("gather", codec, root, i)
+    # (c) both, with a wider stride in the gathered buffer and one image lacking its own buffer
+    outs2 = [torch.zeros(per, dtype=torch.uint8, device=s.device) for s in srcs]
+    outs2[1] = None
+    gathered = torch.zeros((n, per + 64), dtype=torch.uint8, device="cuda:%d" % devices[0])
+    st, _, gathered = pkg.encode_batch_sharded_device(codec, srcs, size, size, comps, devices, etc_strategy=strategy,
+                                                      outs=outs2, gather_device=devices[0], gathered=gathered)
+    assert st == [0] * n
+    g = gathered.cpu().numpy()
+    for i in range(n):
+        assert g[i, :per].tobytes() == want[i] and not g[i, per:].any()
+        if outs2[i] is not None:
+            assert outs2[i].cpu().numpy().tobytes() == want[i]
+
+
+def test_sharded_device_batch_one_gpu_listed_several_times(pkg):
+    for codec, comps, size in ((pkg.DXT1, 3, 256), (pkg.DXT1, 4, 512), (pkg.DXT5, 4, 256), (pkg.ETC1, 3, 128),
+                               (pkg.PVRTC2, 4, 256)):
+        _sharded_case(pkg, codec, comps, size, 7, [0, 0, 0])
+    # argument errors: a bad ordinal is an error status, not a crash; a refused geometry is the reference's `false`
+    import torch
+    src = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda")
+    with pytest.raises(pkg.BackendError):
+        pkg.encode_batch_sharded_device(pkg.DXT1, [src], 64, 64, 4, [0], gather_device=99)
+    st, _, _ = pkg.encode_batch_sharded_device(pkg.PVRTC2, [src], 48, 48, 4, [0], gather_device=0)
+    assert st == [pkg.FALSE]
+
+
+def test_sharded_device_batch_on_distinct_gpus(pkg):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (hipMemcpyPeerAsync over xGMI)")
+    devices = list(range(torch.cuda.device_count()))
+    _sharded_case(pkg, pkg.DXT1, 4, 512, 2 * len(devices) + 1, devices)
+    _sharded_case(pkg, pkg.ETC1, 3, 256, len(devices) + 1, devices)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock(pkg):
+    import torch
+    s = torch.cuda.Stream()
+    res = pkg.clock_probe(20000, s)
+    torch.cuda.synchronize()
+    r = res()
+    assert r is not None and 15.0 < r["interval_ms"] < 200.0
+    assert 100.0 < r["shader_MHz"] < 3000.0, r
+
+
+def test_process_that_used_every_entry_point_exits_cleanly(pkg):
+    """No HIP call may run from a thread_local / static destructor (the runtime can be gone by then): a process that
+    exercised the host-buffer API (thread-local staging), PVRTC (thread-local workspace), worker threads and the batch
+    entry points must exit 0 with no HIP error in its AMD_LOG_LEVEL=1 log."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import ic_amd_loader, ic_testlib as T
+pkg = ic_amd_loader.load_package()
+def work():
+    for compressor, fmt, comps in ((pkg.COMPRESSOR_DXTC, pkg.RGB, 3), (pkg.COMPRESSOR_DXTC, pkg.RGBA, 4),
+                                   (pkg.COMPRESSOR_ETC, pkg.RGB, 3), (pkg.COMPRESSOR_PVRTC, pkg.RGBA, 4)):
+        img = T.s_mixed(64, 64, comps, index=3)
+        out = pkg.compress_host(compressor, fmt, img, 64, 64)
+        assert out is not None
+        if compressor != pkg.COMPRESSOR_PVRTC:
+            assert pkg.pad_host(compressor, fmt, out, 64, 64, 72, 80) is not None
+            assert pkg.downsample_host(compressor, fmt, out, 64, 64) is not None
+    d = torch.from_numpy(T.s_mixed(64, 64, 4, index=5)).cuda()
+    pkg.encode_device(pkg.PVRTC2, d, 64, 64, 4); pkg.encode_device(pkg.DXT5, d, 64, 64, 4)
+    torch.cuda.synchronize()
+work()
+ts = [threading.Thread(target=work) for _ in range(3)]
+[t.start() for t in ts]; [t.join() for t in ts]
+imgs = [T.s_mixed(64, 64, 3, index=i) for i in range(5)]
+assert all(o is not None for o in pkg.compress_batch_host(pkg.COMPRESSOR_DXTC, pkg.RGB, imgs, 64, 64, [0, 0]))
+srcs = [torch.from_numpy(T.s_mixed(64, 64, 4, index=i)).cuda() for i in range(5)]
+st, _, g = pkg.encode_batch_sharded_device(pkg.PVRTC2, srcs, 64, 64, 4, [0, 0], gather_device=0)
+assert st == [0] * 5
+print("WORK DONE")
+''' % (T.ROOT, os.path.join(T.ROOT, "tests"))
+    env = dict(os.environ, AMD_LOG_LEVEL="1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    assert "WORK DONE" in p.stdout
+    bad = [l for l in p.stderr.splitlines() if "hipError" in l or "HIP error" in l or "Assertion" in l or "core dumped" in l]
+    assert not bad, bad[:10]
