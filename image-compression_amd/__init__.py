@@ -426,10 +426,19 @@ def encode_batch_sharded_device(codec, srcs, height, width, src_components, devi
     return list(statuses), outs, gathered
 
 
-def clock_probe(duration_us, stream):
+def clock_probe_buffer():
+    """A zeroed result buffer for clock_probe, allocated and cleared NOW (synchronised): allocate the buffers of all
+    probes before the launches they are to overlap, or the clearing kernel queues up behind those launches."""
+    out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def clock_probe(duration_us, stream, out=None):
     """Enqueues the one-wave clock probe on `stream`; returns a callable that (after a synchronize) yields the mean
     shader clock in MHz over the probe's interval, or None if the counters are unusable."""
-    out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    if out is None:
+        out = clock_probe_buffer()
     khz = lib().icamd_wall_clock_rate_khz()
     st = lib().icamd_clock_probe_device(ctypes.c_void_p(out.data_ptr()), int(duration_us), _stream_handle(stream))
     _check(st, "icamd_clock_probe_device")

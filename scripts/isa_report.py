@@ -20,6 +20,10 @@ CSRC = os.path.join(ROOT, "image-compression_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+FULL_RATE = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32",
+             "v_ashrrev_i32", "v_mov_b32", "v_not_b32"}
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     report = {"command": "hipcc %s -S --cuda-device-only <tu>.hip" % " ".join(f for f in FLAGS if not f.startswith("-I")),
@@ -49,10 +53,19 @@ def main():
                     op = mm.group(1)
                     mix["valu" if op.startswith("v_") else "salu" if op.startswith("s_") else
                         "lds" if op.startswith("ds_") else "vmem"] += 1
+                    # the integer ops that issue at twice the base rate (scripts/ubench_valu.hip, r01: 73 vs 38.6 T
+                    # lane-ops/s): add/sub, and/or/xor, right shifts, mov -- in their plain VOP1/VOP2 encodings
+                    if re.sub(r"_e32$", "", op) in FULL_RATE:
+                        mix["valu_full_rate"] += 1
             granule = (e["vgprs"] + e["agprs"] + 7) // 8 * 8
             by_vgpr = min(8, 512 // max(granule, 8))
             waves_per_wg = max(1, e["workgroup_lanes"] // 64)
             by_lds = 8 if e["lds_bytes"] == 0 else min(8, (160 * 1024 // e["lds_bytes"]) * waves_per_wg // 4)
+            valu = max(1, mix.get("valu", 0))
+            e["valu_full_rate_fraction_static"] = round(mix.get("valu_full_rate", 0) / valu, 4)
+            # issue clocks per executed VALU wave-instruction if the executed mix equals the static one: 4 at the base
+            # rate (16 lanes / clk / SIMD), 2 for the full-rate ops
+            e["valu_issue_clk_per_inst_static"] = round(4.0 - 2.0 * mix.get("valu_full_rate", 0) / valu, 4)
             e.update({"static_instructions": dict(mix), "waves_per_simd_by_vgprs": by_vgpr,
                       "waves_per_simd_by_lds": by_lds, "waves_per_simd": min(by_vgpr, by_lds), "translation_unit": tu})
             report["kernels"][name] = e

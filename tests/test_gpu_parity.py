@@ -825,7 +825,8 @@ def test_sharded_device_batch_one_gpu_listed_several_times(pkg):
     import torch
     src = torch.zeros(64 * 64 * 4, dtype=torch.uint8, device="cuda")
     with pytest.raises(pkg.BackendError):
-        pkg.encode_batch_sharded_device(pkg.DXT1, [src], 64, 64, 4, [0], gather_device=99)
+        pkg.encode_batch_sharded_device(pkg.DXT1, [src], 64, 64, 4, [0], gather_device=99,
+                                        gathered=torch.zeros((1, 2048), dtype=torch.uint8, device="cuda"))
     st, _, _ = pkg.encode_batch_sharded_device(pkg.PVRTC2, [src], 48, 48, 4, [0], gather_device=0)
     assert st == [pkg.FALSE]
 

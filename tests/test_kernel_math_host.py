@@ -83,6 +83,41 @@ def test_block_math_random_blocks(emul):
         assert got == want, (codec, comps, swap, strategy)
 
 
+def dxt_boundary_blocks(g, n, comps):
+    """n 4x4 blocks (as a 4 x 4n strip) built to sit ON the decision boundaries of the DXT colour index search: every
+    pixel is an endpoint, a /3 blend or a midpoint between neighbouring palette entries of two random endpoint colours,
+    plus a jitter of 0 .. +-2; the endpoint distance ranges from 0 (constant path, degenerate palettes whose blends
+    reorder under truncation) to the full cube."""
+    e0 = g.integers(0, 256, size=(n, 1, 3), dtype=np.int64)
+    spread = g.choice(np.array([0, 1, 2, 3, 4, 6, 9, 14, 27, 40, 80, 255]), size=(n, 1, 1))
+    e1 = np.clip(e0 + g.integers(-1, 2, size=(n, 1, 3)) * spread + g.integers(-2, 3, size=(n, 1, 3)), 0, 255)
+    num = g.choice(np.array([0, 1, 2, 3, 4, 5, 6]), size=(n, 16, 1))  # position on the segment in sixths
+    px = (e0 * (6 - num) + e1 * num) // 6 + g.integers(-2, 3, size=(n, 16, 1)) * (g.integers(0, 3, size=(n, 1, 1)) == 0)
+    px = np.clip(px, 0, 255).astype(np.uint8)
+    # make sure both endpoints occur
+    px[:, 0, :] = e0[:, 0, :]
+    px[:, 15, :] = e1[:, 0, :]
+    if comps == 4:
+        px = np.concatenate([px, g.integers(0, 256, size=(n, 16, 1), dtype=np.uint8)], axis=2)
+    # block b, pixel (y, x) -> strip[y, 4 b + x]
+    return np.ascontiguousarray(px.reshape(n, 4, 4, comps).transpose(1, 0, 2, 3).reshape(4, 4 * n, comps))
+
+
+def test_dxt_color_index_search_on_decision_boundaries(emul):
+    """The O(1) colour index search of dxt_block.h (sorted-palette thresholds, r03) and its fall-back scan against the
+    oracle's four-candidate scan (dxtc.cc:315-349) on blocks constructed to hit ties and degenerate palettes."""
+    g = np.random.Generator(np.random.PCG64(303))
+    n = 1 << 17
+    for codec, comps, swap in ((T.DXT1, 3, 0), (T.DXT1, 3, 1), (T.DXT1, 4, 0), (T.DXT5, 4, 0), (T.DXT5, 4, 1)):
+        strip = dxt_boundary_blocks(g, n, comps)
+        want = T.oracle_encode(codec, strip, 4, 4 * n, comps, swap, 2)
+        got = emul_encode(emul, codec, strip, 4, 4 * n, comps, swap, 2)
+        if got != want:
+            bb = 16 if codec == T.DXT5 else 8
+            bad = [i for i in range(n) if got[i * bb:(i + 1) * bb] != want[i * bb:(i + 1) * bb]]
+            raise AssertionError((codec, comps, swap, len(bad), bad[:5]))
+
+
 def test_pvrtc_math_matches_oracle(emul):
     for n in (8, 16, 32, 64, 128):
         for gen in ("noise", "smooth", "flat", "mixed"):
