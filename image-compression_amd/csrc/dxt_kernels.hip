@@ -71,58 +71,11 @@ __device__ __forceinline__ void dxt_encode_two(const GridParams &P) {
   }
 }
 
-// A/B variant (r03): two HORIZONTALLY adjacent blocks per lane, 512 x 1-block tiles -- a lane reads
-// 24 contiguous bytes per pixel row (one 16-byte + one 8-byte load; a wave 1 536 contiguous bytes) and writes its two
-// blocks with one 16-byte store.  Built only with -DICAMD_RGB888_HPAIR (profiles/r03_ab_rgb888_hpair.log has the result).
-#if defined(ICAMD_RGB888_HPAIR)
-__device__ __forceinline__ void dxt1_rgb888_hpair(const GridParams &P) {
-  __shared__ uint32_t lds_px[4][kThreadsPerWorkgroup][4];
-  BlockStash stash;
-  stash.base = &lds_px[0][threadIdx.x][0];
-  const bool swap = P.swap_rb != 0;
-  const uint32_t brow = blockIdx.y + P.tile_row0, bcol0 = blockIdx.x * 512u, bcol = bcol0 + 2u * threadIdx.x;
-  const uint32_t img = blockIdx.z;
-  if (bcol >= P.block_cols) return;
-  const bool interior = (bcol0 + 512u) * 4u <= P.width && (brow + 1u) * 4u <= P.height && !P.force_gather;
-  uint32_t px[2][16];
-  const uint8_t *image = P.src + (uint64_t)img * P.src_image_stride;
-  if (interior) {
-    const uint8_t *base = image + (uint64_t)(brow * 4u) * P.row_stride + (uint64_t)bcol0 * 12u;
-    const uint32_t off = threadIdx.x * 24u;
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const uint8_t *row = base + (uint32_t)(off + (uint32_t)y * P.row_stride);
-      const U4 a = load_stream(reinterpret_cast<const U4 *>(row));
-      const U2 b = *reinterpret_cast<const U2 *>(row + 16);
-      px[0][4 * y + 0] = a.x;
-      px[0][4 * y + 1] = alignbit(a.y, a.x, 24);
-      px[0][4 * y + 2] = alignbit(a.z, a.y, 16);
-      px[0][4 * y + 3] = a.z >> 8;
-      px[1][4 * y + 0] = a.w;
-      px[1][4 * y + 1] = alignbit(b.x, a.w, 24);
-      px[1][4 * y + 2] = alignbit(b.y, b.x, 16);
-      px[1][4 * y + 3] = b.y >> 8;
-    }
-  } else {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      if (bcol + h < P.block_cols)
-        load_block<3>(image, P.height, P.width, P.row_stride, brow * 4u, (bcol + h) * 4u, px[h], !P.force_gather);
-  }
-  uint8_t *dst = P.dst + (uint64_t)img * P.dst_image_stride + ((uint64_t)brow * P.block_cols + bcol) * 8u;
-  const Out8 c0 = encode_dxt_color_block(px[0], swap, false, stash);
-  if (bcol + 1u < P.block_cols) {
-    const Out8 c1 = encode_dxt_color_block(px[1], swap, false, stash);
-    store_stream16(dst, c0.lo, c0.hi, c1.lo, c1.hi);
-  } else {
-    store_stream8(dst, c0.lo, c0.hi);
-  }
-}
-extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_hpair_kernel(GridParams P) { dxt1_rgb888_hpair(P); }
-#endif
-
 extern "C" {
 
+// (r03: two HORIZONTALLY adjacent blocks per lane -- 24 contiguous bytes per row as a 16-byte + an 8-byte load, one
+// 16-byte store, 512 x 1-block tiles -- measured 10 % slower than this kernel on every content,
+// profiles/r03_ab_rgb888_hpair.log; the variant is in the history at commit "DXT colour index search in O(1)".)
 // 3-byte sources only (r02 A/B, 16 x 4096^2, ms per launch, one block vs two blocks per lane): RGB888 0.183 -> 0.175
 // (noise), 0.190 -> 0.183 (flat), 0.174 -> 0.172 (smooth); RGBA8 0.190 -> 0.201 and DXT5 0.253 -> 0.259 got slower
 // (67-71 VGPRs instead of 51-54) and keep one block per lane.
@@ -148,16 +101,6 @@ hipError_t launch_dxt(int codec, int comps, const GridParams &P, hipStream_t str
     return launch_tiled(icamd_dxt5_rgba8_kernel, icamd_dxt5_rgba8_narrow_kernel, P, stream);
   }
   if (comps == 4) return launch_tiled(icamd_dxt1_rgba8_kernel, icamd_dxt1_rgba8_narrow_kernel, P, stream);
-#if defined(ICAMD_RGB888_HPAIR)
-  if (P.block_cols > 256 && (uint64_t)P.row_stride * 4u < (1ull << 31) && P.block_rows <= 65535u && P.n_images <= 65535u) {
-    GridParams Q = P;
-    Q.log2_tile_cols = 8; Q.tile_row0 = 0;
-    Q.force_gather = (uint64_t)P.row_stride * 3u + 16384u >= (1ull << 32) ? 1u : 0u;
-    hipLaunchKernelGGL(icamd_dxt1_rgb888_hpair_kernel, dim3((P.block_cols + 511u) / 512u, P.block_rows, P.n_images),
-                       dim3(kThreadsPerWorkgroup), 0, stream, Q);
-    return hipGetLastError();
-  }
-#endif
   return launch_tiled(icamd_dxt1_rgb888_x2_kernel, icamd_dxt1_rgb888_narrow_kernel, P, stream, 8, 2);
 }
 

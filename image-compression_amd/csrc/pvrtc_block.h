@@ -472,25 +472,48 @@ ICAMD_DEV void pvrtc_encode_block_rows(RowLoader &load, const PvrtcColors nb[3][
 // twice; only the last block of a strip still pays for it.  A block is finished (its mode decided, its words stored)
 // right after row 0 of the block under it.  44 -> 36 + 8/K modulation values per block.
 struct PvrtcBlockAcc {
-  uint32_t inter, hc, vc, d1, d2;
+  uint32_t hc, vc, d1, d2;
+  uint32_t u01, u23;    // rows (0, 1) / (2, 3): byte x = m(x, y) | m(x + 4, y) << 2 | m(x, y + 1) << 4 | m(x + 4, y + 1) << 6
+  uint32_t col0, col7;  // EXCHANGE only: byte y = modulation of pixel (0, y) / (7, y) of the block
 };
-// one pixel row (y = 0..3, compile-time after unrolling) of a block: everything except the vertical differences
+// one pixel row (y = 0..3, compile-time after unrolling) of a block: everything except the vertical differences.
+// The bit gathers of CalculateBlockModulationData (pvrtc.cc:456-496) are v_dot4_u32_u8 with power-of-two weights: the
+// modulation values sit one per byte, so  sum_x (m_x & 2) * 2^x  is twice the row's eight 1BPP bits, and
+// sum_j m_(2j + odd row) * 4^j  its four checkerboard samples (2 bits each) -- one dot per half row instead of a
+// shift-mask-multiply-shift chain (r03).
+// EXCHANGE: the value right of the row is not computed here -- the term |m(7, y) - m(8, y)| is added when the block is
+// finished, from the right-hand neighbour's own column-0 values (pvrtc_encode_strip); the row only records its two
+// outer values.
+template <bool EXCHANGE>
 ICAMD_DEV void pvrtc_acc_row(PvrtcBlockAcc &A, int y, const uint32_t row[2], uint32_t right_mod) {
   A.vc = sad_u8(row[0], alignbit(row[1], row[0], 8), A.vc);   // "vertical_count" = sum |m - m(x+1, y)| (pvrtc.cc:426-429)
-  A.vc = sad_u8(row[1], alignbit(right_mod, row[1], 8), A.vc);
-  ICAMD_UNROLL
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t m = row[h];
-    A.inter += popcount_u32((m ^ (m >> 1)) & 0x01010101u);  // values 1 or 2: low bit xor high bit
-    const int pos = 8 * y + 4 * h;
-    A.d1 |= ((((m >> 1) & 0x01010101u) * 0x01020408u) >> 24) << pos;  // 1BPP: bit 8y+x = m >> 1
-    const uint32_t v = ((y & 1) ? m >> 8 : m) & 0x00030003u;           // 2BPP: checkerboard samples
-    A.d2 |= ((v | v >> 14) & 0xfu) << pos;
+  if (EXCHANGE) {
+    A.vc = sad_u8(row[1], perm(row[1], row[1], 0x03030201u), A.vc);  // bytes (5, 6, 7, 7): the last term is 0 here
+    // byte y of col0 / col7 <- byte 0 of row[0] / byte 3 of row[1]; selector 4 + i keeps byte i of the old value
+    const uint32_t keep = 0x07060504u & ~(0xffu << (8 * y));
+    A.col0 = perm(A.col0, row[0], keep);
+    A.col7 = perm(A.col7, row[1], keep | 0x03u << (8 * y));
+  } else {
+    A.vc = sad_u8(row[1], alignbit(right_mod, row[1], 8), A.vc);
   }
+  // 1BPP word: bit 8y + x = m >> 1
+  const uint32_t twice = udot4(row[1] & 0x02020202u, 0x80402010u, udot4(row[0] & 0x02020202u, 0x08040201u, 0u));
+  A.d1 |= y == 0 ? twice >> 1 : twice << (8 * y - 1);
+  // 2BPP word: the samples with (x ^ y) & 1 == 0, 2 bits each, raster order -> byte y
+  const uint32_t w0 = (y & 1) ? 0x04000100u : 0x00040001u, w1 = (y & 1) ? 0x40001000u : 0x00400010u;
+  A.d2 |= udot4(row[1], w1, udot4(row[0], w0, 0u)) << (8 * y);
+  // values 1 or 2 are counted at the end, two rows per dword
+  const uint32_t u = row[0] | row[1] << 2;
+  if (y == 0) A.u01 = u;
+  else if (y == 1) A.u01 |= u << 4;
+  else if (y == 2) A.u23 = u;
+  else A.u23 |= u << 4;
 }
 ICAMD_DEV uint32_t pvrtc_acc_finish(const PvrtcBlockAcc &A, bool *mode_1bpp) {
+  // pixels best served by an intermediate value (1 or 2): low bit xor high bit of each 2-bit field
+  const uint32_t inter = popcount_u32((A.u01 ^ (A.u01 >> 1)) & 0x55555555u) + popcount_u32((A.u23 ^ (A.u23 >> 1)) & 0x55555555u);
   uint32_t mode = 1u;  // 0 = 1BPP, 1 = average-4, 2 = vertical, 3 = horizontal (pvrtc.cc:433-446)
-  if (A.inter <= 4u) mode = 0u;
+  if (inter <= 4u) mode = 0u;
   else if (A.vc > 10u && A.vc > A.hc * 2u) mode = 2u;
   else if (A.hc > 10u && A.hc > A.vc * 2u) mode = 3u;
   uint32_t d2 = mode == 1u ? (A.d2 & ~1u) : (A.d2 | 1u);  // pvrtc.cc:474-487
@@ -499,19 +522,41 @@ ICAMD_DEV uint32_t pvrtc_acc_finish(const PvrtcBlockAcc &A, bool *mode_1bpp) {
   return mode == 0u ? A.d1 : d2;
 }
 
+// Modulation value of the pixel at x_in = 0, row y_in (0..3, a RUN-TIME value) of a block, from the reduced colours of
+// the four blocks its interpolation uses: columns (left neighbour, own) x block rows (upper, lower), where (upper,
+// lower) = (by - 1, by) for y_in < 2 and (by, by + 1) otherwise (pvrtc.cc:216-227).  With xw = 4 the four bilinear
+// weights are 4 (4 - yw), 4 (4 - yw), 4 yw, 4 yw, so the /32 of Interpolate4_2BPP is an exact >> 3 of
+// (4 - yw)(c00 + c01) + yw (c10 + c11) (<= 2040 per 16-bit lane).  Used once per strip by the encode kernel for the
+// column right of each wave (the lanes in between get these values from their right-hand neighbour lane).
+ICAMD_DEV uint32_t pvrtc_left_edge_mod(uint32_t pixel, uint32_t y_in, const PvrtcColors &ul, const PvrtcColors &uc,
+                                       const PvrtcColors &ll, const PvrtcColors &lc) {
+  const uint32_t yw = (y_in + 2u) & 3u, uw = 4u - yw;
+  const uint32_t a_rb = ((uw * (pair_rb(ul.a) + pair_rb(uc.a)) + yw * (pair_rb(ll.a) + pair_rb(lc.a))) >> 3) & 0x00ff00ffu;
+  const uint32_t a_ga = ((uw * (pair_ga(ul.a) + pair_ga(uc.a)) + yw * (pair_ga(ll.a) + pair_ga(lc.a))) >> 3) & 0x00ff00ffu;
+  const uint32_t b_rb = ((uw * (pair_rb(ul.b) + pair_rb(uc.b)) + yw * (pair_rb(ll.b) + pair_rb(lc.b))) >> 3) & 0x00ff00ffu;
+  const uint32_t b_ga = ((uw * (pair_ga(ul.b) + pair_ga(uc.b)) + yw * (pair_ga(ll.b) + pair_ga(lc.b))) >> 3) & 0x00ff00ffu;
+  return best_modulation(pixel, a_rb, a_ga, b_rb, b_ga);
+}
+
 // load_px(r, pixels[8], &right): pixel row r of the strip, r = 0 .. 4 K (row 4 K = first row of the block below the
 //                                strip), and the pixel right of it; toroidal wrap is the loader's business.
 // load_colours(j, c[3]):         reduced colours of block row j of the strip (j = -1 .. K), columns left/centre/right.
 // store(j, data, mode_1bpp, own): block j of the strip is finished; own = its reduced colours.
+// EXCHANGE: the modulation values right of a block (pvrtc.cc:426-429 looks one pixel right) are not computed by the
+//   lane -- 4 of the 37 values a block costs -- but fetched when block j is finished:
+// right_of(j, col0):             given this lane's column-0 values of block j (byte y = row y), returns those of the
+//                                block to its right.  On the device consecutive lanes are consecutive block columns
+//                                walking the same rows in lock-step, so this is a one-lane shuffle (the last lane of a
+//                                wave reads values its workgroup computed up front with pvrtc_left_edge_mod).
 //
 // The walk is organised by COLOUR-ROW PAIRS, not by blocks: rows 2, 3 of block s-1 and rows 0, 1 of block s all
 // interpolate between the colours of block rows s-1 (A) and s (B), with vertical weights 0, 1, 2, 3
 // (pvrtc.cc:216-227).  So the twelve vertical blends 8 ((4 - yw) A + yw B) of a pixel row are set up once per four
 // rows (32 A, and the step 8 (B - A)) and then just stepped -- twelve full-rate adds per row instead of re-expanding
 // six colours and re-blending them; two pixel-row buffers alternate, so no row is ever copied.
-template <typename PixelRowLoader, typename ColourRowLoader, typename BlockStore>
+template <bool EXCHANGE, typename PixelRowLoader, typename ColourRowLoader, typename BlockStore, typename RightOf>
 ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, ColourRowLoader &load_colours,
-                                  BlockStore &store) {
+                                  BlockStore &store, RightOf &right_of) {
   PvrtcColors cc[3];
   uint32_t A[3][4];  // colour row s-1 as channel pairs
   load_colours(-1, cc);
@@ -524,7 +569,7 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
   ICAMD_UNROLL
   for (int i = 0; i < 8; ++i) buf1[i] = 0;
   load_px(0u, buf0, &right0);
-  PvrtcBlockAcc acc = { 0, 0, 0, 0, 0 };
+  PvrtcBlockAcc acc = { 0, 0, 0, 0, 0, 0, 0, 0 };
   PvrtcColors own = cc[1];
   ICAMD_NOUNROLL
   for (uint32_t s = 0;; ++s) {
@@ -548,10 +593,10 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
       // rows 2 and 3 of block s-1: weights 0 and 1
       load_px(4u * s - 1u, buf1, &right1);
       ICAMD_SCHED_FENCE();
-      pvrtc_row_mods_v<true>(V, buf0, right0, row, &right_mod);
+      pvrtc_row_mods_v<!EXCHANGE>(V, buf0, right0, row, &right_mod);
       acc.hc = sad_u8(prev[0], row[0], acc.hc);  // "horizontal_count" = sum |m - m(x, y+1)| (pvrtc.cc:426-429)
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
-      pvrtc_acc_row(acc, 2, row, right_mod);
+      pvrtc_acc_row<EXCHANGE>(acc, 2, row, right_mod);
       prev[0] = row[0]; prev[1] = row[1];
       ICAMD_UNROLL
       for (int c = 0; c < 3; ++c)
@@ -560,10 +605,10 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
       ICAMD_SCHED_FENCE();
       load_px(4u * s, buf0, &right0);
       ICAMD_SCHED_FENCE();
-      pvrtc_row_mods_v<true>(V, buf1, right1, row, &right_mod);
+      pvrtc_row_mods_v<!EXCHANGE>(V, buf1, right1, row, &right_mod);
       acc.hc = sad_u8(prev[0], row[0], acc.hc);
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
-      pvrtc_acc_row(acc, 3, row, right_mod);
+      pvrtc_acc_row<EXCHANGE>(acc, 3, row, right_mod);
       prev[0] = row[0]; prev[1] = row[1];
       ICAMD_UNROLL
       for (int c = 0; c < 3; ++c)
@@ -579,18 +624,19 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
     // row 0 of block s, weight 2 -- for s == k_blocks the row below the strip, which only completes block K-1
     if (s < k_blocks) load_px(4u * s + 1u, buf1, &right1);
     ICAMD_SCHED_FENCE();
-    pvrtc_row_mods_v<true>(V, buf0, right0, row, &right_mod);
+    pvrtc_row_mods_v<!EXCHANGE>(V, buf0, right0, row, &right_mod);
     if (s > 0) {  // the vertical differences across the block boundary, then block s-1 is complete
       acc.hc = sad_u8(prev[0], row[0], acc.hc);
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      if (EXCHANGE) acc.vc = sad_u8(acc.col7, right_of(s - 1u, acc.col0), acc.vc);  // sum_y |m(7, y) - m(8, y)|
       bool one_bpp;
       const uint32_t data = pvrtc_acc_finish(acc, &one_bpp);
       store(s - 1u, data, one_bpp, own);
     }
     if (s == k_blocks) break;
     own = own_next;
-    acc.inter = acc.hc = acc.vc = acc.d1 = acc.d2 = 0;
-    pvrtc_acc_row(acc, 0, row, right_mod);
+    acc.hc = acc.vc = acc.d1 = acc.d2 = 0;  // (u01 / u23 / col0 / col7 are overwritten piece by piece)
+    pvrtc_acc_row<EXCHANGE>(acc, 0, row, right_mod);
     prev[0] = row[0]; prev[1] = row[1];
     ICAMD_UNROLL
     for (int c = 0; c < 3; ++c)
@@ -600,10 +646,10 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
     // row 1 of block s, weight 3
     load_px(4u * s + 2u, buf0, &right0);
     ICAMD_SCHED_FENCE();
-    pvrtc_row_mods_v<true>(V, buf1, right1, row, &right_mod);
+    pvrtc_row_mods_v<!EXCHANGE>(V, buf1, right1, row, &right_mod);
     acc.hc = sad_u8(prev[0], row[0], acc.hc);
     acc.hc = sad_u8(prev[1], row[1], acc.hc);
-    pvrtc_acc_row(acc, 1, row, right_mod);
+    pvrtc_acc_row<EXCHANGE>(acc, 1, row, right_mod);
     prev[0] = row[0]; prev[1] = row[1];
     ICAMD_SCHED_FENCE();
   }
@@ -686,6 +732,14 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
         }
       for (int y = 0; y < 4; ++y) right |= (uint32_t)mods[(size_t)(by * 4 + y) * n + ((bx * 8 + 8) & (n - 1))] << (8 * y);
       for (int x = 0; x < 8; ++x) below[x >> 2] |= (uint32_t)mods[(size_t)((by * 4 + 4) & (n - 1)) * n + bx * 8 + x] << (8 * (x & 3));
+      // pvrtc_left_edge_mod (what the encode kernel precomputes for the column right of each wave) == the per-pixel path
+      for (uint32_t y = 0; y < 4; ++y) {
+        const uint32_t up = (y < 2 ? by + bh - 1 : by) % bh, dn = (up + 1) % bh, lx = (bx + bw - 1) % bw;
+        const PvrtcColors ul = { ca[up * bw + lx], cb[up * bw + lx] }, uc = { ca[up * bw + bx], cb[up * bw + bx] };
+        const PvrtcColors ll = { ca[dn * bw + lx], cb[dn * bw + lx] }, lc = { ca[dn * bw + bx], cb[dn * bw + bx] };
+        if (pvrtc_left_edge_mod(img[(size_t)(by * 4 + y) * n + bx * 8], y, ul, uc, ll, lc) !=
+            mods[(size_t)(by * 4 + y) * n + bx * 8]) return 0;
+      }
       // the halo values each lane recomputes for itself must equal the neighbours' own values
       if (right != self_right[by * bw + bx] || below[0] != self_below[2 * (by * bw + bx)] ||
           below[1] != self_below[2 * (by * bw + bx) + 1]) return 0;
@@ -736,7 +790,20 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
           const uint32_t *o = reinterpret_cast<const uint32_t *>(out) + 2 * (size_t)pvrtc_z_index(bx, by0 + j);
           if (o[0] != data || o[1] != pvrtc_pack_colors(own.a, own.b, one_bpp)) ok = 0;
         };
-        pvrtc_encode_strip(k_blocks, load_px, load_colours, store);
+        auto no_right = [&](uint32_t, uint32_t) -> uint32_t { return 0u; };
+        pvrtc_encode_strip<false>(k_blocks, load_px, load_colours, store, no_right);
+        if (!ok) return 0;
+        // EXCHANGE form: the right-hand values come from the neighbouring column (here: the per-pixel reference path)
+        auto right_of = [&](uint32_t j, uint32_t col0) -> uint32_t {
+          uint32_t own0 = 0, r = 0;
+          for (int y = 0; y < 4; ++y) {
+            own0 |= (uint32_t)mods[(size_t)((by0 + j) * 4 + y) * n + bx * 8] << (8 * y);
+            r |= (uint32_t)mods[(size_t)((by0 + j) * 4 + y) * n + ((bx * 8 + 8) & (n - 1))] << (8 * y);
+          }
+          if (own0 != col0) ok = 0;  // what the lane hands to its left-hand neighbour
+          return r;
+        };
+        pvrtc_encode_strip<true>(k_blocks, load_px, load_colours, store, right_of);
         if (!ok) return 0;
       }
   delete[] ab; delete[] ca; delete[] cb; delete[] mods; delete[] self_right; delete[] self_below;

@@ -289,7 +289,15 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rec
 // bits, pvrtc.cc:80-86) = one contiguous run of the output.  Chunk stride padded by two slots against bank conflicts.
 constexpr uint32_t kStageSlots = (kEncodeLanes / 8) * 66;  // sb = 3: 32 chunks x (64 + 2) slots of 8 bytes
 
-__device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds) {
+// EXCHANGE (regions at least 64 block columns wide, i.e. every whole texture of 512^2 and more): a lane does not
+// compute the modulation values right of its blocks (4 of the 37 a block costs) -- its right-hand neighbour LANE owns
+// that block column and walks the same pixel rows in lock-step, so the four values of a block arrive with one
+// one-lane shuffle when the block is finished.  Only the last lane of a wave has no neighbour in the wave: the values
+// right of ITS strip (4 << log2_strip pixel rows) are computed up front by the workgroup, one pixel per lane
+// (pvrtc_left_edge_mod), parked in 128 bytes of LDS, and the single barrier of the kernel follows -- before the strips
+// start, where it costs nothing.  -9 % executed instructions per block (r03).
+template <bool EXCHANGE>
+__device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds, uint32_t *lds_edge) {
   uint2 *lds_out = reinterpret_cast<uint2 *>(lds);
   const uint32_t k = wg * kEncodeLanes + threadIdx.x;
   const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
@@ -303,6 +311,30 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     by0 = L.ry0 + ((s >> L.log2_rw) << sb);
   };
   const uint32_t chunk_slots = (1u << (2u * sb)) + 2u;
+  if (EXCHANGE) {
+    // lane t < 4 * rows: pixel row r = t % rows of the strip of wave w = t / rows, in the block column right of that
+    // wave's last lane; byte r of the wave's 32-byte LDS row = its modulation value
+    const uint32_t log2_rows = 2u + sb, t = threadIdx.x;
+    if (t < (4u << log2_rows)) {
+      const uint32_t w = t >> log2_rows, r = t & ((1u << log2_rows) - 1u);
+      const uint32_t kk = wg * kEncodeLanes + 64u * w + 63u;
+      if (kk < L.total_strips) {
+        uint32_t image, bx, by0;
+        locate(kk, image, bx, by0);
+        const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+        const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
+        const uint32_t cx = (bx + 1u) & bw_mask, y_in = r & 3u;
+        const uint32_t by = (by0 + (r >> 2)) & bh_mask;
+        const uint32_t up = (y_in < 2u ? by - 1u : by) & bh_mask, dn = (up + 1u) & bh_mask;
+        const uint2 ul = ab[(up << L.log2_bw) + bx], uc = ab[(up << L.log2_bw) + cx];
+        const uint2 ll = ab[(dn << L.log2_bw) + bx], lc = ab[(dn << L.log2_bw) + cx];
+        const uint32_t pixel = img[(size_t)((by0 * 4u + r) & (n - 1u)) * n + cx * 8u];
+        const PvrtcColors c_ul = { ul.x, ul.y }, c_uc = { uc.x, uc.y }, c_ll = { ll.x, ll.y }, c_lc = { lc.x, lc.y };
+        reinterpret_cast<uint8_t *>(lds_edge)[w * 32u + r] = (uint8_t)pvrtc_left_edge_mod(pixel, y_in, c_ul, c_uc, c_ll, c_lc);
+      }
+    }
+    __syncthreads();
+  }
   if (k < L.total_strips) {
     uint32_t image, bx, by0;
     locate(k, image, bx, by0);
@@ -317,7 +349,7 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
       const uint4 v0 = *reinterpret_cast<const uint4 *>(q + bx * 8u), v1 = *reinterpret_cast<const uint4 *>(q + bx * 8u + 4);
       pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
       pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
-      *right_px = q[xr * 8u];
+      if (!EXCHANGE) *right_px = q[xr * 8u];
     };
     auto load_colours = [&](int j, PvrtcColors c[3]) {
       const uint2 *row = ab + (((by0 + (uint32_t)j) & bh_mask) << L.log2_bw);
@@ -335,7 +367,14 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
       if (L.stage_stores) slot0[spread_bits16(j)] = v;
       else dst[(zx | spread_bits16(by0 + j)) - L.z_first] = v;
     };
-    pvrtc_encode_strip(1u << sb, load_px, load_colours, store);
+    // column-0 values of the block to the right: lane + 1's own; the wave's last lane reads the precomputed ones
+    const uint32_t *edge_row = lds_edge + (threadIdx.x >> 6) * 8u;
+    const bool wave_end = (threadIdx.x & 63u) == 63u;
+    auto right_of = [&](uint32_t j, uint32_t col0) -> uint32_t {
+      const uint32_t from_lane = (uint32_t)__shfl_down((int)col0, 1);
+      return wave_end ? edge_row[j] : from_lane;
+    };
+    pvrtc_encode_strip<EXCHANGE>(1u << sb, load_px, load_colours, store, right_of);
   }
   if (!L.stage_stores) return;
   // Write-out: every lane stores 16 bytes (two Z-adjacent blocks) per round; 32 lanes cover one 512-byte run (sb = 3).
@@ -361,7 +400,14 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
 
 extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
   __shared__ uint32_t lds[kStageSlots * 2];
-  pvrtc2_encode(L, blockIdx.x, lds);
+  __shared__ uint32_t lds_edge[4 * 8];  // per wave: 32 bytes = the values right of its last lane's strip
+  pvrtc2_encode<true>(L, blockIdx.x, lds, lds_edge);
+}
+// regions fewer than 64 block columns wide (textures below 512^2): a wave holds several strip rows, every lane computes
+// the values right of its blocks itself
+extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_narrow_kernel(PvrtcLaunch L) {
+  __shared__ uint32_t lds[kStageSlots * 2];
+  pvrtc2_encode<false>(L, blockIdx.x, lds, nullptr);
 }
 
 const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_encode_kernel"; }
@@ -416,7 +462,8 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
   const dim3 gm((rw + 2 + kMorphLanes - 1) / kMorphLanes, rh + 2), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
   hipLaunchKernelGGL(icamd_pvrtc2_morph_rect_kernel, gm, dim3(kMorphLanes), 0, stream, L);
-  hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, L);
+  hipLaunchKernelGGL(L.log2_rw >= 6 ? icamd_pvrtc2_encode_kernel : icamd_pvrtc2_encode_narrow_kernel, ge, dim3(kEncodeLanes),
+                     0, stream, L);
   e = hipGetLastError();
   const hipError_t e2 = ws.release(stream);
   return e != hipSuccess ? e : e2;
@@ -486,7 +533,8 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
     else if (Q.log2_bw >= 6) hipLaunchKernelGGL(icamd_pvrtc2_morph_dense_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
     else hipLaunchKernelGGL(icamd_pvrtc2_morph_kernel, gm, dim3(kMorphLanes), 0, stream, Q);
-    hipLaunchKernelGGL(icamd_pvrtc2_encode_kernel, ge, dim3(kEncodeLanes), 0, stream, Q);
+    hipLaunchKernelGGL(Q.log2_rw >= 6 ? icamd_pvrtc2_encode_kernel : icamd_pvrtc2_encode_narrow_kernel, ge,
+                       dim3(kEncodeLanes), 0, stream, Q);
   }
   e = hipGetLastError();
   const hipError_t e2 = ws.release(stream);
