@@ -34,7 +34,6 @@ ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
   uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
   return (ah > bh ? ah - bh : 0u) << 16 | (al > bl ? al - bl : 0u);
 }
-ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
 ICAMD_DEV uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
   return (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16) + c;
 }
@@ -49,7 +48,6 @@ ICAMD_DEV uint32_t pk_subsat_u16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(icamd_us2, a),
                                                                      __builtin_bit_cast(icamd_us2, b)));
 }
-ICAMD_DEV uint32_t popcount32(uint32_t v) { return (uint32_t)__popc(v); }
 // v_dot2_u32_u16: a.lo * b.lo + a.hi * b.hi + c
 ICAMD_DEV uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {
   return __builtin_amdgcn_udot2(__builtin_bit_cast(icamd_us2, a), __builtin_bit_cast(icamd_us2, b), c, false);
@@ -135,37 +133,25 @@ struct EtcSubResult {
 // E0 = 2 p.base - |base|^2.  Then (all comparisons exact integers, same tie rules as etc.cc:366-379):
 //   * the sign of s picks the side: s >= 0 -> {+a, +b} (indices 0,1), s < 0 -> {-a, -b} (indices 2,3);
 //     f(+m) - f(-m) = 4 m s, and s = 0 ties go to the lower index, i.e. the positive side;
-//   * within the side, +/-a wins unless 2b|s| - 3b^2 > 2a|s| - 3a^2 (tie -> a, the lower index).
-// Per pixel and codeword that is 2 v_mad_i32_i24 + v_max_i32 instead of 4 dot4 + 4 shift-adds + 2 max.
-// abs_s[j] = |s| of pixel j of the sub-block.  Returns Sum_j max_m (2 m s - 3 m^2) (WITHOUT the E0 part);
-// *abits gets, in bits 24..31, bit j = 1 iff pixel j chose modifier magnitude a.
-ICAMD_DEV int32_t eval_codeword_unclamped(const uint32_t abs_s[8], int32_t a, int32_t b, uint32_t *abits) {
-  int32_t sum = 0;
-  uint32_t acc = 0;
+//   * within the side, +/-a wins unless 2b|s| - 3b^2 > 2a|s| - 3a^2, i.e. a wins iff 2|s| <= 3 (a + b)  (tie -> a).
+// So a pixel contributes  f = max(2a|s| - 3a^2, 2b|s| - 3b^2) = (2a|s| - 3a^2) + (b - a) relu(2|s| - 3(a + b)),  and with
+// relu(y) = (y + |y|) / 2 the sub-block's score collapses to sums (r03):
+//     Sum_j f_j = ( (a + b) S2 + (b - a) Sum_j |2|s_j| - 3(a + b)| ) / 2  -  12 (a^2 + b^2),     S2 = Sum_j 2|s_j|
+// (the numerator is even: S2 is, and either b - a is or all eight terms of the second sum are odd).  Per pixel and
+// codeword that is ONE v_sad_u16 with accumulate; which modifier each pixel took is worked out afterwards, for the
+// winning codeword only (search_codewords).  abs2[j] = 2|s_j| of pixel j of the sub-block.  Returns Sum_j f_j (WITHOUT
+// the E0 part).
+ICAMD_DEV int32_t eval_codeword_unclamped(const uint32_t abs2[8], uint32_t s2, int32_t a, int32_t b) {
+  uint32_t dev = 0;
   ICAMD_UNROLL
-  for (int j = 0; j < 8; ++j) {
-    const int32_t ka = imad24((int32_t)abs_s[j], 8 * a, 1 - 12 * a * a);  // 4 f(a) + 1: a wins ties
-    const int32_t kb = imad24((int32_t)abs_s[j], 8 * b, 0 - 12 * b * b);  // 4 f(b)
-    const int32_t m = imax(ka, kb);
-    sum += m;
-    acc = alignbit((uint32_t)m, acc, 1);
-  }
-  *abits = acc;
-  return (sum - (int32_t)popcount32(acc)) >> 2;  // keys are 4 f + tie bit: exact division
-}
-
-// 8 bits (bit j = pixel j) -> 16 bits (bit 2j)
-ICAMD_DEV uint32_t spread_bits8(uint32_t v) {
-  v = (v | v << 4) & 0x0f0fu;
-  v = (v | v << 2) & 0x3333u;
-  v = (v | v << 1) & 0x5555u;
-  return v;
+  for (int j = 0; j < 8; ++j) dev = sad_u32(abs2[j], (uint32_t)(3 * (a + b)), dev);
+  return (imad24(a + b, (int32_t)s2, imad24(b - a, (int32_t)dev, 0)) >> 1) - 12 * (a * a + b * b);
 }
 
 // FindBestCodeword (etc.cc:391-409): first codeword with the strictly smallest error.
 // bmin / bmax: smallest / largest channel of the decoded base colour (decides, per codeword and for the whole
 // wave at once, whether the unclamped shortcut applies); sub_sum[]: channel sums of the sub-block's 8 pixels;
-// psum[]: r+g+b of each of the 16 pixels.
+// psum[]: 2 (r + g + b) of each of the 16 pixels.
 template <int FLIP, int S>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
                                         const uint32_t bch[3], const uint32_t sub_sum[3]) {
@@ -175,15 +161,15 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // `fast` is a wave-uniform flag that only ever goes from true to false, and when even codeword 0 clamps (bright /
   // dark / saturated regions) none of the shortcut's per-pixel preparation is executed.
   bool fast = wave_all(bmin >= (uint32_t)kEtcB[0] && bmax + (uint32_t)kEtcB[0] <= 255u);
-  // per pixel |s| and the sign bits (bit 24+j = 1 iff s < 0), shared by all unclamped codewords
-  uint32_t abs_s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, negbits = 0;
+  // per pixel 2|s| (psum[] holds 2 (r + g + b)) and their sum, shared by all unclamped codewords
+  const uint32_t bsum2 = 2u * bsum;
+  uint32_t abs2[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, s2 = 0;
   int32_t e0_sum = 0;
   if (fast) {
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) {
-      const uint32_t sp = psum[sub_pixel<FLIP, S>(j)];
-      abs_s[j] = sad_u32(sp, bsum, 0u);
-      negbits = alignbit((sp - bsum) >> 31, negbits, 1);
+      abs2[j] = sad_u32(psum[sub_pixel<FLIP, S>(j)], bsum2, 0u);
+      s2 += abs2[j];
     }
     // Sum_j E0 = 2 * (base . sub_sum) - 8 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
     e0_sum = 2 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
@@ -251,7 +237,8 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     }
     if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
     if (fast) {
-      s = eval_codeword_unclamped(abs_s, kEtcA[cw], kEtcB[cw], &f) + e0_sum;
+      s = eval_codeword_unclamped(abs2, s2, kEtcA[cw], kEtcB[cw]) + e0_sum;
+      f = 0u;  // worked out below if this codeword wins
       fast_mask |= 1u << cw;
     } else {
       uint32_t v[4];
@@ -264,10 +251,21 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     r.cw = better ? (uint32_t)cw : r.cw;
     r.fields = better ? f : r.fields;
   }
-  // the winner's index fields in the common format (3 - k per pixel, 2 bits, bits 16..31):
-  // shortcut -> high bit = (s >= 0), low bit = (magnitude a chosen)
-  const uint32_t from_fast = (spread_bits8(r.fields >> 24) | spread_bits8((~negbits) >> 24) << 1) << 16;
-  r.fields = ((fast_mask >> r.cw) & 1u) ? from_fast : r.fields;
+  // The winner's index fields in the common format (3 - k per pixel, 2 bits, bits 16..31) when it took the shortcut:
+  // high bit = (s >= 0), low bit = (magnitude a chosen) = (2|s| <= 3 (a + b)).  Both are sign bits of one subtraction,
+  // shifted in pixel 7 first; skipped when no lane of the wave was won by a shortcut codeword.
+  const bool won_fast = ((fast_mask >> r.cw) & 1u) != 0u;
+  if (!wave_all(!won_fast)) {
+    const uint32_t sh = (r.cw & 3u) * 8u;
+    const uint32_t thr = 3u * (bfe(r.cw < 4u ? kEtcModA_lo : kEtcModA_hi, sh, 8) + bfe(r.cw < 4u ? kEtcModB_lo : kEtcModB_hi, sh, 8));
+    uint32_t acc = 0;
+    ICAMD_UNROLL
+    for (int j = 7; j >= 0; --j) {
+      acc = alignbit(acc, psum[sub_pixel<FLIP, S>(j)] - bsum2, 31);  // s < 0
+      acc = alignbit(acc, thr - abs2[j], 31);                          // 2|s| > 3 (a + b): magnitude b
+    }
+    r.fields = won_fast ? ~acc << 16 : r.fields;
+  }
   return r;
 }
 
@@ -396,9 +394,9 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
       qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
     }
   }
-  uint32_t psum[16];  // r+g+b per pixel (for the unclamped shortcut)
+  uint32_t psum[16];  // 2 (r + g + b) per pixel (for the unclamped shortcut)
   ICAMD_UNROLL
-  for (int p = 0; p < 16; ++p) psum[p] = udot4(px[p], 0x00010101u, 0u);
+  for (int p = 0; p < 16; ++p) psum[p] = udot4(px[p], 0x00020202u, 0u);
   uint32_t left[3], right[3], top[3], bottom[3];
   ICAMD_UNROLL
   for (int ch = 0; ch < 3; ++ch) {

@@ -322,3 +322,38 @@ def test_pvrtc_decode_properties():
     dec = T.oracle_decode(T.PVRTC2, T.oracle_encode(T.PVRTC2, img, 256, 256, 4), 256, 256).reshape(256, 256, 4)
     mse = ((dec.astype(np.float64) - img) ** 2).mean()
     assert 10 * np.log10(255 * 255 / mse) > 30.0
+
+
+def etc_shortcut_blocks(g, n, comps):
+    """n 4x4 blocks (4 x 4n strip) aimed at the unclamped shortcut of etc1_block.h: mid-tone base colours (so that the
+    shortcut applies up to some codeword) with per-pixel deviations drawn around the decision points 2|s| = 3 (a + b)
+    of every codeword (s = pixel sum - base sum), plus plain jitter of several amplitudes."""
+    base = g.integers(40, 216, size=(n, 1, 3), dtype=np.int64)
+    thr = np.array([15, 33, 57, 82, 117, 156, 208, 345])[g.integers(0, 8, size=(n, 16, 1))]  # 3 (a + b) / 2
+    sign = g.choice(np.array([-1, 1]), size=(n, 16, 1))
+    mode = g.integers(0, 3, size=(n, 1, 1))
+    near = sign * (thr + g.integers(-2, 3, size=(n, 16, 1)))          # pixel sum deviation near a threshold
+    split = g.integers(0, 3, size=(n, 16, 1))
+    dev = np.zeros((n, 16, 3), np.int64)
+    for c in range(3):                                                 # spread the deviation over the channels
+        dev[:, :, c:c + 1] = near // 3 + (split == c) * (near - 3 * (near // 3))
+    jitter = g.integers(-1, 2, size=(n, 16, 3)) * np.array([1, 4, 24])[g.integers(0, 3, size=(n, 1, 1))]
+    px = np.where(mode == 0, base + dev, np.where(mode == 1, base + jitter, base + dev + jitter))
+    px = np.clip(px, 0, 255).astype(np.uint8)
+    if comps == 4:
+        px = np.concatenate([px, g.integers(0, 256, size=(n, 16, 1), dtype=np.uint8)], axis=2)
+    return np.ascontiguousarray(px.reshape(n, 4, 4, comps).transpose(1, 0, 2, 3).reshape(4, 4 * n, comps))
+
+
+def test_etc1_unclamped_shortcut_on_decision_points(emul):
+    """The sum form of the ETC1 unclamped shortcut (one v_sad per pixel and codeword, winner's modifiers worked out
+    afterwards; r03) against the oracle's exhaustive scan (etc.cc:350-409), all search strategies."""
+    g = np.random.Generator(np.random.PCG64(404))
+    n = 1 << 15
+    for comps, strategy in ((3, 2), (3, 0), (3, 1), (4, 2)):
+        strip = etc_shortcut_blocks(g, n, comps)
+        want = T.oracle_encode(T.ETC1, strip, 4, 4 * n, comps, 0, strategy)
+        got = emul_encode(emul, T.ETC1, strip, 4, 4 * n, comps, 0, strategy)
+        if got != want:
+            bad = [i for i in range(n) if got[i * 8:(i + 1) * 8] != want[i * 8:(i + 1) * 8]]
+            raise AssertionError((comps, strategy, len(bad), bad[:5]))
