@@ -42,8 +42,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# integer VALU issue peak: 1 024 SIMDs x 2.4 GHz, one wave instruction per 4 clocks at the 16 lanes/clk base rate
-VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4.0
 
 # name -> (codec id, source components, algorithmic bytes per pixel (read + write), label, limiting unit)
 WORKLOADS = {
@@ -429,6 +427,48 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     }
 
 
+def valu_fraction(args, codec, pixels_per_launch, kernel_ms, clock_mhz):
+    """Integer-VALU issue fraction of the sustained run, from measured quantities only:
+      executed VALU wave-instructions per kernel  -- SQ_INSTS_VALU of the committed PMC profile of EXACTLY this workload /
+                                                    content / ETC strategy (profiles/valu_insts.json);
+      issue clocks per instruction                -- 4 at the base rate (16 lanes / clk / SIMD: the measured ceiling of
+                                                    scripts/ubench_valu.hip, 38.6 T lane-ops/s at 2.36 GHz), 2 for the
+                                                    add / sub / and / or / xor / right-shift / mov ops that issue at twice
+                                                    that rate, weighted with each kernel's static mix (profiles/*_isa.json);
+      clock                                       -- the shader clock the probe measured during this run (or 2 400 MHz
+                                                    nominal when the probe is unavailable, which is then said so)."""
+    vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
+    if not os.path.exists(vpath):
+        return None
+    with open(vpath) as f:
+        vi = json.load(f).get("%s/%s/s%d" % (args.workload, args.content, args.etc_strategy if codec == 2 else 0))
+    if not vi:
+        return None
+    isa = {}
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_isa.json"):
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                isa = json.load(f).get("kernels", {})
+            break
+    mpix = pixels_per_launch / 1e6
+    per_kernel = vi.get("per_kernel_valu_wave_insts_per_Mpixel") or {}
+    clocks, detail = 0.0, {}
+    if per_kernel:
+        for k, ipm in per_kernel.items():
+            cpi = (isa.get(k) or {}).get("valu_issue_clk_per_inst_static", 4.0)
+            clocks += ipm * mpix * cpi
+            detail[k] = {"valu_wave_insts": round(ipm * mpix), "issue_clk_per_inst": cpi}
+    else:
+        clocks = vi["valu_wave_insts_per_Mpixel"] * mpix * 4.0
+    mhz = clock_mhz or 2400.0
+    return {"valu_frac": round(clocks / (1024 * mhz * 1e6) / (kernel_ms * 1e-3), 3),
+            "valu_wave_insts_per_block": vi.get("valu_wave_insts_per_block_lane"),
+            "valu_profile": vi.get("profile"), "valu_kernels": detail,
+            "valu_clock_MHz": mhz if clock_mhz else "2400 nominal (no probe)",
+            "valu_frac_note": "executed VALU wave-instructions x issue clocks (4; 2 for full-rate ops, static mix) / "
+                              "(1024 SIMDs x measured shader clock x sustained kernel time)"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -627,21 +667,8 @@ def main():
             "algorithmic_bytes_per_pixel": bytes_per_px, "algorithmic_bytes_per_launch": int(algo_bytes),
             "read_roofline_frac": round((pixels_per_step_rank * comps / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS, 4),
         }
-        # VALU issue fraction: executed wave-level VALU instructions per Mpixel from the committed PMC profile of
-        # EXACTLY this workload / content / strategy (profiles/valu_insts.json, written by scripts/summarize_profiles.py
-        # from SQ_INSTS_VALU), against 1 024 SIMDs x 2.4 GHz / 4 clk.  Omitted when no matching profile exists.
-        vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
-        if os.path.exists(vpath):
-            with open(vpath) as f:
-                vi = json.load(f).get("%s/%s/s%d" % (args.workload, args.content, args.etc_strategy if codec == 2 else 0))
-            if vi:
-                insts = vi["valu_wave_insts_per_Mpixel"] * pixels_per_step_rank / 1e6
-                result["roofline"]["valu_frac"] = round(insts / VALU_PEAK_WAVE_INSTS / (kernel_ms * 1e-3), 3)
-                result["roofline"]["valu_wave_insts_per_block"] = vi.get("valu_wave_insts_per_block_lane")
-                result["roofline"]["valu_profile"] = vi.get("profile")
-                result["roofline"]["valu_frac_note"] = ("executed VALU wave instructions x 4 clk / (1024 SIMDs x 2.4 GHz x "
-                                                        "kernel time); add/and/or/shift/mov issue at twice that rate, so "
-                                                        "a kernel rich in them can read slightly above 1")
+        result["roofline"]["traffic_source"] = None if traffic is None else \
+            "profiles/traffic.json: FETCH_SIZE * 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes of this workload (not measured in this run)"
         import ic_testlib as T
         host0 = src[0].cpu().numpy()
         if not args.no_verify:
@@ -681,6 +708,9 @@ def main():
                 mhz = (clock.get("last_25pct") or {}).get("shader_MHz")
                 if mhz:
                     result["roofline"]["effective_clock_MHz"] = mhz
+                vf = valu_fraction(args, codec, pixels_per_step_rank, sus["median_ms_last_20pct"], mhz)
+                if vf:
+                    result["roofline"].update(vf)
             except Exception as e:
                 result["sustained"] = "unavailable: %s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_single_image:

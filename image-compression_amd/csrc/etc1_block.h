@@ -148,11 +148,41 @@ ICAMD_DEV int32_t eval_codeword_unclamped(const uint32_t abs2[8], uint32_t s2, i
   return (imad24(a + b, (int32_t)s2, imad24(b - a, (int32_t)dev, 0)) >> 1) - 12 * (a * a + b * b);
 }
 
+// Mixed tier: the codeword's +/-a candidates are unclamped in every lane of the wave (base_c +/- a inside [0,255]) while
+// +/-b may clamp somewhere.  +/-a then follow the formula -- the better of the two is on the side of sign(s), with
+// E = E0 + 2a|s| - 3a^2 -- and only +/-b are built and evaluated exactly: per pixel one v_mad + 2 (v_dot4 + v_lshl_add)
+// + v_max3 instead of 4 (v_dot4 + v_lshl_add) + v_max3 + v_max.  k0[j] = 32 E0_j + (3 - k) of the a candidate on the
+// pixel's side (k = 0 for s >= 0, 2 for s < 0); all keys of this evaluation carry a common offset of +96 a^2, taken off
+// the sum at the end.  Same key format and tie rules as eval_codeword.
+template <int FLIP, int S>
+ICAMD_DEV int32_t eval_codeword_mixed(const uint32_t px[16], const uint32_t abs2[8], const int32_t k0[8], const EtcBase &base,
+                                      int32_t a, int32_t b, uint32_t *fields) {
+  const uint32_t b2 = (uint32_t)b * 0x01000100u, b1 = (uint32_t)b << 8, sel = 0x0c050107u;
+  const uint32_t vp = perm(pk_addsat_u16(base.rb_hi, b2), pk_addsat_u16(base.g_hi, b1), sel);
+  const uint32_t vn = perm(pk_subsat_u16(base.rb_hi, b2), pk_subsat_u16(base.g_hi, b1), sel);
+  const int32_t cp = (int32_t)opaque((uint32_t)(2 + 96 * a * a - 32 * (int32_t)udot4(vp, vp, 0u)));  // k = 1
+  const int32_t cn = (int32_t)opaque((uint32_t)(0 + 96 * a * a - 32 * (int32_t)udot4(vn, vn, 0u)));  // k = 3
+  int32_t sum = 0;
+  uint32_t acc = 0;
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t p = px[sub_pixel<FLIP, S>(j)];
+    const int32_t ka = imad24((int32_t)abs2[j], 32 * a, k0[j]);
+    const int32_t kp = (int32_t)(udot4(p, vp, 0u) << 6) + cp;
+    const int32_t kn = (int32_t)(udot4(p, vn, 0u) << 6) + cn;
+    const int32_t m = imax3(ka, kp, kn);
+    sum += m;
+    acc = alignbit((uint32_t)m, acc, 2);
+  }
+  *fields = acc;
+  return (sum >> 5) - 24 * a * a;
+}
+
 // FindBestCodeword (etc.cc:391-409): first codeword with the strictly smallest error.
 // bmin / bmax: smallest / largest channel of the decoded base colour (decides, per codeword and for the whole
 // wave at once, whether the unclamped shortcut applies); sub_sum[]: channel sums of the sub-block's 8 pixels;
 // psum[]: 2 (r + g + b) of each of the 16 pixels.
-template <int FLIP, int S>
+template <int FLIP, int S, bool TIER>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
                                         const uint32_t bch[3], const uint32_t sub_sum[3]) {
   const uint32_t bsum = bch[0] + bch[1] + bch[2];
@@ -164,7 +194,9 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // per pixel 2|s| (psum[] holds 2 (r + g + b)) and their sum, shared by all unclamped codewords
   const uint32_t bsum2 = 2u * bsum;
   uint32_t abs2[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, s2 = 0;
+  int32_t k0[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
   int32_t e0_sum = 0;
+  bool a_fits = false;       // mixed tier usable (set below); then wave-uniform and monotone like `fast`
   if (fast) {
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) {
@@ -190,6 +222,19 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
   // a per-channel deviation is at least a third of the L1 one, and no step exceeds a_7 = 47
   bool prunable = wave_all(d1 < 3u * (uint32_t)kEtcA[7]);
+  // Mixed tier (eval_codeword_mixed) for the codewords the shortcut does not reach: prepared only on busy content --
+  // where pruning is on, most of those codewords are skipped anyway.
+  if (TIER && fast && !prunable && !wave_all(bmin >= (uint32_t)kEtcB[7] && bmax + (uint32_t)kEtcB[7] <= 255u)) {
+    a_fits = true;
+    // 32 E0_j + tie field of the a candidate on the pixel's side (3 for s >= 0, 1 for s < 0)
+    const int32_t c3 = 3 - 32 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t q = sub_pixel<FLIP, S>(j);
+      const int32_t neg = (int32_t)(psum[q] - bsum2) >> 31;  // -1 iff s < 0
+      k0[j] = (int32_t)(udot4(px[q], base_px, 0u) << 6) + c3 + 2 * neg;
+    }
+  }
   uint32_t dev_rb = 0, dev_g = 0;      // per-channel maximum deviation: R | B << 16, G
   uint32_t room_rb_up = 0, room_rb_dn = 0, room_g_up = 0, room_g_dn = 0;
   int32_t sum_sq = 0;                  // Sum_j |p_j|^2: error of a codeword = sum_sq - its score
@@ -241,10 +286,15 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       f = 0u;  // worked out below if this codeword wins
       fast_mask |= 1u << cw;
     } else {
-      uint32_t v[4];
-      int32_t c[4];
-      build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
-      s = eval_codeword<FLIP, S>(px, v, c, &f);
+      if (TIER && a_fits) a_fits = wave_all(bmin >= (uint32_t)kEtcA[cw] && bmax + (uint32_t)kEtcA[cw] <= 255u);
+      if (TIER && a_fits) {
+        s = eval_codeword_mixed<FLIP, S>(px, abs2, k0, base, kEtcA[cw], kEtcB[cw], &f);
+      } else {
+        uint32_t v[4];
+        int32_t c[4];
+        build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
+        s = eval_codeword<FLIP, S>(px, v, c, &f);
+      }
     }
     const bool better = cw == 0 || s > r.score;
     r.score = better ? s : r.score;
@@ -302,7 +352,7 @@ struct EtcFlipResult {
 };
 
 // FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
-template <int FLIP>
+template <int FLIP, bool TIER = false>
 ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
                                     const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
@@ -342,8 +392,8 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
     r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
     r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
   } else {
-    r0 = search_codewords<FLIP, 0>(px, psum, e0, b0, s0);
-    r1 = search_codewords<FLIP, 1>(px, psum, e1, b1, s1);
+    r0 = search_codewords<FLIP, 0, TIER>(px, psum, e0, b0, s0);
+    r1 = search_codewords<FLIP, 1, TIER>(px, psum, e1, b1, s1);
   }
   EtcFlipResult out;
   out.hi = hi | r0.cw << 5 | r1.cw << 2;
@@ -379,6 +429,27 @@ ICAMD_DEV uint32_t assemble_indices(uint32_t f0, uint32_t f1, bool flip) {
 
 // EncodeEtc1Block (etc.cc:545-586).  Source channel order is always R,G,B (EtcCompressor accepts kRGB
 // only, etc.cc:751-754).  Returns the 8 output bytes: hi word then lo word, each big-endian (etc.cc:172-180).
+// Wave-uniform content probe for the kSmallerError kernels: true when at least three quarters of the wave's blocks have
+// pixels whose sums r + g + b spread by 2 * 141 or more -- such a block has a pixel at least 141 (L1) from any colour it
+// could average to, which switches the pruning of its searches off (search_codewords: d1 >= 3 * 47) and makes the mixed
+// tier what its exact evaluations want.  The instantiation with the tier runs ~5 % slower wherever the tier is not used
+// (register pressure), so a wave of mostly calm blocks takes the one without.  Only a performance choice: both produce
+// the same bytes.
+ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  ICAMD_UNROLL
+  for (int p = 0; p < 16; ++p) {
+    const uint32_t t = udot4(px[p], 0x00020202u, 0u);  // the same 2 (r + g + b) the searches use
+    lo = umin(lo, t);
+    hi = umax(hi, t);
+  }
+  return wave_count(hi - lo >= 4u * 141u) >= 48u;
+}
+
+// TIER: compile the mixed tier (eval_codeword_mixed) into the codeword searches.  It pays on busy content only and its
+// mere presence costs smooth / flat content 3-5 % (r03 A/B), so the kSmallerError kernels carry both instantiations and
+// pick one per wave (etc1_busy_wave).
+template <bool TIER = false>
 ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
   uint32_t qs[4][3];
@@ -408,10 +479,10 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   EtcFlipResult res;
   bool flip;
   if (strategy == 0u) {  // kSplitHorizontally: top|bottom only
-    res = encode_flip<1>(px, psum, top, bottom, false);
+    res = encode_flip<1, TIER>(px, psum, top, bottom, false);
     flip = true;
   } else if (strategy == 1u) {  // kSplitVertically: left|right only
-    res = encode_flip<0>(px, psum, left, right, false);
+    res = encode_flip<0, TIER>(px, psum, left, right, false);
     flip = false;
   } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574: one evaluation, partition chosen per lane
     // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
@@ -446,8 +517,8 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
     res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u);
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
-    const EtcFlipResult r0 = encode_flip<0>(px, psum, left, right, false);
-    const EtcFlipResult r1 = encode_flip<1>(px, psum, top, bottom, false);
+    const EtcFlipResult r0 = encode_flip<0, TIER>(px, psum, left, right, false);
+    const EtcFlipResult r1 = encode_flip<1, TIER>(px, psum, top, bottom, false);
     // error_lr <= error_tb  <=>  score_lr >= score_tb  (same Sum|p|^2 on both sides)
     flip = !(r0.score >= r1.score);
     res.hi = flip ? r1.hi : r0.hi;

@@ -7,20 +7,40 @@
 
 namespace icamd {
 
-template <int COMPS, bool WIDE>
+// STRATEGY is a compile-time constant: one kernel per EtcCompressor::CompressionStrategy, so that the straight-line
+// code of kSmallerError (two partitions x two sub-blocks x eight codewords, unrolled) does not carry the single-partition
+// and heuristic paths along -- the kernel is bound by instruction issue AND sensitive to its code footprint
+// (profiles/r03_ab_etc1_*.log).  The default: label of etc_compressor.cc:575-584 makes every other value kSmallerError.
+template <int COMPS, int STRATEGY>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = locate_tile<WIDE>(P);
+  const TileCoord t = locate_tile<false>(P);
   if (!t.valid) return;
   uint32_t px[16];
   load_tile_block<COMPS>(P, t, px);
-  const Out8 c = encode_etc1_block(px, P.etc_strategy);
+  Out8 c;
+  if (STRATEGY == 3) c = encode_etc1_block<false>(px, 3u);
+  else if (etc1_busy_wave(px)) c = encode_etc1_block<true>(px, (uint32_t)STRATEGY);  // per wave: with the mixed tier ...
+  else c = encode_etc1_block<false>(px, (uint32_t)STRATEGY);                          // ... or without (smooth / flat content)
   store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
 }
 
 extern "C" {
 
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgb888_kernel(GridParams P) { etc1_encode_one<3, false>(P); }
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_rgba8_kernel(GridParams P) { etc1_encode_one<4, false>(P); }
+// (amdgpu_waves_per_eu(4): the search must fit 128 VGPRs -- left alone the allocator takes 139 for kSmallerError with the
+// mixed tier, i.e. 3 waves per SIMD, which costs smooth / flat content 10-18 %)
+#define ICAMD_ETC1_KERNEL(name, comps, strategy)                                                                      \
+  __global__ void __launch_bounds__(kThreadsPerWorkgroup) __attribute__((amdgpu_waves_per_eu(4))) name(GridParams P) { \
+    etc1_encode_one<comps, strategy>(P);                                                                              \
+  }
+ICAMD_ETC1_KERNEL(icamd_etc1_rgb888_kernel, 3, 2)        // kSmallerError (the reference's default)
+ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_kernel, 4, 2)
+ICAMD_ETC1_KERNEL(icamd_etc1_rgb888_split_h_kernel, 3, 0)  // kSplitHorizontally
+ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_split_h_kernel, 4, 0)
+ICAMD_ETC1_KERNEL(icamd_etc1_rgb888_split_v_kernel, 3, 1)  // kSplitVertically
+ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_split_v_kernel, 4, 1)
+ICAMD_ETC1_KERNEL(icamd_etc1_rgb888_heuristic_kernel, 3, 3)  // kHeuristic
+ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_heuristic_kernel, 4, 3)
+#undef ICAMD_ETC1_KERNEL
 
 }  // extern "C"
 
@@ -31,8 +51,12 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   // decisions (unclamped shortcut, codeword pruning) fire far more often on compact waves, and at 7 % of the HBM
   // roofline the narrower loads cost nothing: noise 1.47 = 1.47 ms, smooth 1.85 -> 1.61 ms, flat 1.90 -> 1.72 ms (r01)
   const uint32_t cap = 4u;
-  return comps == 4 ? launch_tiled(icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_kernel, P, stream, cap)
-                    : launch_tiled(icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_kernel, P, stream, cap);
+  typedef void (*Kernel)(GridParams);
+  static const Kernel kernels[2][4] = {
+    { icamd_etc1_rgb888_split_h_kernel, icamd_etc1_rgb888_split_v_kernel, icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_heuristic_kernel },
+    { icamd_etc1_rgba8_split_h_kernel, icamd_etc1_rgba8_split_v_kernel, icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_heuristic_kernel } };
+  const Kernel k = kernels[comps == 4 ? 1 : 0][P.etc_strategy < 4u ? P.etc_strategy : 2u];
+  return launch_tiled(k, k, P, stream, cap);
 }
 
 }  // namespace icamd

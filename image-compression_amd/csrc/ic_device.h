@@ -146,8 +146,11 @@ ICAMD_DEV int32_t imax(int32_t a, int32_t b) { return max(a, b); }
 // True iff the predicate holds in every active lane of the wave (the emulation has one "lane").
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV bool wave_all(bool p) { return p; }
+ICAMD_DEV uint32_t wave_count(bool p) { return p ? 64u : 0u; }
 #else
 ICAMD_DEV bool wave_all(bool p) { return __all(p ? 1 : 0) != 0; }
+// number of active lanes of the wave in which the predicate holds
+ICAMD_DEV uint32_t wave_count(bool p) { return (uint32_t)__popcll(__ballot(p ? 1 : 0)); }
 #endif
 
 // Value the optimiser must treat as freshly produced (blocks common-subexpression elimination across uses).

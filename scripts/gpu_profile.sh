@@ -1,7 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats for every bench workload, plus separate
-# PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950) for the HBM traffic of each kernel, plus
-# SQ-only passes for the other contents / ETC1 strategies (executed VALU instructions per workload/content/strategy).
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel traces for every bench workload, plus separate PMC passes
+# (FETCH_SIZE / WRITE_SIZE cannot share a pass on gfx950) for the HBM traffic of each kernel, plus SQ-only passes for
+# the other contents / ETC1 strategies (executed VALU instructions per workload/content/strategy).
+# The trace pass runs the bench the way the driver does plus 0.5 s of untimed preconditioning launches, 100 timed
+# steps; scripts/summarize_profiles.py takes its statistics from the LAST 100 launches of each kernel (the timed
+# ones), so warm-up and preconditioning launches are excluded.  PMC passes: 20 + 3 launches, no preconditioning.
 # Output: gpurun_out/prof/<tag>/..., summarised by scripts/summarize_profiles.py into profiles/.
 # Usage: scripts/gpu_profile.sh [workload ...]
 set -u
@@ -12,9 +15,11 @@ rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 WLS=${@:-dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8}
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+COMMON="--no-cpu-baseline --no-verify --no-host-api --no-sustained --no-single-image"
 for wl in $WLS; do
-  B="python bench.py --steps 20 --warmup 3 --workload $wl --no-cpu-baseline --no-verify --no-host-api"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$wl/trace" -o "$wl" -- $B > "$O/$wl.trace.log" 2>&1
+  T="python bench.py --steps 100 --warmup 5 --precondition-seconds 0.5 --workload $wl $COMMON"
+  B="python bench.py --steps 20 --warmup 3 --precondition-seconds 0 --workload $wl $COMMON"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$wl/trace" -o "$wl" -- $T > "$O/$wl.trace.log" 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/$wl/pmc_fetch" -o "$wl" -- $B > "$O/$wl.fetch.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/$wl/pmc_write" -o "$wl" -- $B > "$O/$wl.write.log" 2>&1
   rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d "$O/$wl/pmc_sq" -o "$wl" -- $B > "$O/$wl.sq.log" 2>&1
@@ -28,7 +33,21 @@ case " $WLS " in *" etc1_rgb888 "*)
   for s in 0 1 3; do
     tag=etc1_rgb888__noise__s$s
     rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$O/$tag/pmc_sq" -o "$tag" -- \
-      python bench.py --steps 20 --warmup 3 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline --no-verify --no-host-api > "$O/$tag.sq.log" 2>&1
+      python bench.py --steps 20 --warmup 3 --precondition-seconds 0 --workload etc1_rgb888 --etc-strategy $s $COMMON > "$O/$tag.sq.log" 2>&1
   done;;
 esac
+# keep the merge small: the raw kernel traces of the preconditioned runs are reduced to per-launch duration lists
+python - <<'PY'
+import csv, glob, os
+for f in glob.glob(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/prof/*/trace/*kernel_trace.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("icamd_")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    t0 = int(rows[0]["Start_Timestamp"]) if rows else 0
+    with open(f.replace("kernel_trace.csv", "timeline.csv"), "w") as out:
+        out.write("kernel,start_us,duration_us\n")
+        for r in rows:
+            out.write("%s,%.1f,%.2f\n" % (r["Kernel_Name"], (int(r["Start_Timestamp"]) - t0) / 1e3,
+                                          (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    os.remove(f)
+PY
 find "$O" -name '*.csv' | wc -l

@@ -27,8 +27,11 @@ def counters(path):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+STEPS_UNDER_PROFILER = int(os.environ.get("ICAMD_PROFILE_LAUNCHES", "23"))  # gpu_profile.sh: --steps 20 --warmup 3
+
+
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(DST, exist_ok=True)
     tpath = os.path.join(DST, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -48,12 +51,30 @@ def main():
             for r in rows:
                 w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
-        summary = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 "
-                   "--workload %s --no-cpu-baseline --no-verify --no-host-api" % wl, "kernels": {}}
+        summary = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 "
+                   "--precondition-seconds 0.5 --workload %s --no-cpu-baseline --no-verify --no-host-api --no-sustained "
+                   "--no-single-image" % wl, "kernels": {}}
         for r in rows:
             if r["Name"].startswith("icamd_"):
                 summary["kernels"][r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
-                                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+                                                 "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3,
+                                                 "note": "rocprofv3 --stats over ALL launches incl. preconditioning and warm-up"}
+        # the timed launches only: the last 100 of each kernel in the per-launch timeline
+        tl = os.path.join(d, "trace", wl + "_timeline.csv")
+        if os.path.exists(tl):
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(tl)):
+                per[r["kernel"]].append(float(r["duration_us"]))
+            with open(os.path.join(DST, "%s_%s_timeline_last100.csv" % (rnd, wl)), "w") as f:
+                f.write("kernel,launch_from_end,duration_us\n")
+                for k, v in per.items():
+                    for i, x in enumerate(v[-100:]):
+                        f.write("%s,%d,%.2f\n" % (k, len(v[-100:]) - i, x))
+            for k, v in per.items():
+                last = sorted(v[-100:])
+                e = summary["kernels"].setdefault(k, {})
+                e["timed_launches"] = {"n": len(last), "avg_us": round(sum(last) / len(last), 2), "median_us": last[len(last) // 2],
+                                       "min_us": last[0], "max_us": last[-1], "launches_before_them": len(v) - len(last)}
         fetch = counters(os.path.join(d, "pmc_fetch", wl + "_counter_collection.csv"))
         write = counters(os.path.join(d, "pmc_write", wl + "_counter_collection.csv"))
         sq = counters(os.path.join(d, "pmc_sq", wl + "_counter_collection.csv"))
@@ -64,7 +85,7 @@ def main():
                 e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2  # gfx950 half-count correction
                 e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
                 e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-                steps = 23.0  # bench.py --steps 20 --warmup 3 under the profiler
+                steps = float(STEPS_UNDER_PROFILER)  # launches of the bench step under the profiler
                 per_step[wl] = per_step.get(wl, 0.0) + e["hbm_bytes_per_launch"] * e.get("calls", steps) / steps
             if "SQ_INSTS_VALU" in e and "SQ_WAVES" in e:
                 e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
@@ -96,12 +117,14 @@ def main():
         insts = sum(v for (k, c), v in sq.items() if c == "SQ_INSTS_VALU")
         if insts <= 0:
             continue
+        per_kernel = {k: v / mpix for (k, c), v in sq.items() if c == "SQ_INSTS_VALU"}
         calls_per_step = 1.0
         if wl.startswith("pvrtc"):
             pass  # morph + encode: one launch each per step, summed
         key = "%s/%s/%s" % (wl, content, strat if wl.startswith("etc1") else "s0")
         lanes_per_block = 32.0 if wl.startswith("pvrtc") else 16.0  # pixels per block
         valu[key] = {"valu_wave_insts_per_Mpixel": insts * calls_per_step / mpix,
+                     "per_kernel_valu_wave_insts_per_Mpixel": per_kernel,
                      "valu_wave_insts_per_block_lane": round(insts * 64.0 / (mpix * 1e6 / lanes_per_block), 1),
                      "profile": "%s: rocprofv3 --pmc SQ_INSTS_VALU, bench.py --workload %s --content %s%s" % (
                          rnd, wl, content, " --etc-strategy %s" % strat[1:] if wl.startswith("etc1") else "")}

@@ -38,7 +38,11 @@ extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_
         memcpy(o, &a, 8);
         memcpy(o + 8, &c, 8);
       } else {
-        Out8 c = encode_etc1_block(px, (uint32_t)strategy);
+        // like the kernel: the instantiation with the mixed tier for "busy" blocks, without it otherwise; bits 8 / 9 of
+        // `strategy` force one of the two for every block (both must produce the reference's bytes on any content)
+        const uint32_t st = (uint32_t)strategy & 0xffu;
+        const bool tier = (strategy & 0x100) ? true : (strategy & 0x200) ? false : (st != 3u && etc1_busy_wave(px));
+        Out8 c = tier ? encode_etc1_block<true>(px, st) : encode_etc1_block<false>(px, st);
         memcpy(o, &c, 8);
       }
     }
