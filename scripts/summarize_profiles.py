@@ -27,9 +27,6 @@ def counters(path):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
-STEPS_UNDER_PROFILER = int(os.environ.get("ICAMD_PROFILE_LAUNCHES", "23"))  # gpu_profile.sh: --steps 20 --warmup 3
-
-
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
     os.makedirs(DST, exist_ok=True)
@@ -85,8 +82,8 @@ def main():
                 e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2  # gfx950 half-count correction
                 e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
                 e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-                steps = float(STEPS_UNDER_PROFILER)  # launches of the bench step under the profiler
-                per_step[wl] = per_step.get(wl, 0.0) + e["hbm_bytes_per_launch"] * e.get("calls", steps) / steps
+                # every kernel of a workload is launched once per bench step (PVRTC: morph + encode)
+                per_step[wl] = per_step.get(wl, 0.0) + e["hbm_bytes_per_launch"]
             if "SQ_INSTS_VALU" in e and "SQ_WAVES" in e:
                 e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
         bj = os.path.join(SRC, wl + ".bench.json")
