@@ -84,8 +84,9 @@ constexpr int sub_pixel(int j) {
 // The 4 candidate colours of one codeword (modifiers +a, +b, -a, -b; etc.cc:121-125 clamps each
 // channel to 0..255) as packed R,G,B,0 dwords, and the per-candidate constant (3-k) - 32|v|^2.
 ICAMD_DEV void build_candidates(const EtcBase &base, uint32_t a, uint32_t b, uint32_t v[4], int32_t c[4]) {
-  const uint32_t a2 = a * 0x01000100u, b2 = b * 0x01000100u;  // modifier in the high byte of both halves
   const uint32_t a1 = a << 8, b1 = b << 8;
+  const uint32_t a2 = a1 | a1 << 16, b2 = b1 | b1 << 16;  // modifier in the high byte of both halves (no multiply: a
+                                                          // run-time modifier -- kHeuristic -- would make it a v_mul_lo_u32)
   // byte0 = R (rb byte 3), byte1 = G (g byte 1), byte2 = B (rb byte 1), byte3 = 0
   const uint32_t sel = 0x0c050107u;
   v[0] = perm(pk_addsat_u16(base.rb_hi, a2), pk_addsat_u16(base.g_hi, a1), sel);
@@ -186,6 +187,7 @@ template <int FLIP, int S, bool TIER>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
                                         const uint32_t bch[3], const uint32_t sub_sum[3]) {
   const uint32_t bsum = bch[0] + bch[1] + bch[2];
+  const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;  // the base colour as a pixel dword
   const uint32_t bmin = umin3(bch[0], bch[1], bch[2]), bmax = umax3(bch[0], bch[1], bch[2]);
   // The modifiers grow with the codeword, so once a codeword clamps somewhere in the wave every later one does too:
   // `fast` is a wave-uniform flag that only ever goes from true to false, and when even codeword 0 clamps (bright /
@@ -204,8 +206,8 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       s2 += abs2[j];
     }
     // Sum_j E0 = 2 * (base . sub_sum) - 8 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
-    e0_sum = 2 * (int32_t)(bch[0] * sub_sum[0] + bch[1] * sub_sum[1] + bch[2] * sub_sum[2]) -
-           8 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
+    e0_sum = 2 * (int32_t)umad24(bch[0], sub_sum[0], umad24(bch[1], sub_sum[1], umad24(bch[2], sub_sum[2], 0u))) -
+           8 * (int32_t)udot4(base_px, base_px, 0u);
   }
   // Wave-uniform exact pruning of codewords that cannot win.  In channel c every candidate on the positive side of
   // codeword cw (+a, +b) differs from the base colour by at least min(a_cw, 255 - base_c), every one on the negative
@@ -216,7 +218,6 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // keeps the FIRST codeword with the strictly smallest error (etc.cc:401), so nothing it would pick is lost.  Two
   // stages keep the cost off busy content: the L1 deviation (one v_sad_u8 per pixel) decides for the whole wave
   // whether the per-channel deviations are worth computing at all.
-  const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;
   uint32_t d1 = 0;
   ICAMD_UNROLL
   for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
@@ -227,7 +228,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   if (TIER && fast && !prunable && !wave_all(bmin >= (uint32_t)kEtcB[7] && bmax + (uint32_t)kEtcB[7] <= 255u)) {
     a_fits = true;
     // 32 E0_j + tie field of the a candidate on the pixel's side (3 for s >= 0, 1 for s < 0)
-    const int32_t c3 = 3 - 32 * (int32_t)(bch[0] * bch[0] + bch[1] * bch[1] + bch[2] * bch[2]);
+    const int32_t c3 = 3 - 32 * (int32_t)udot4(base_px, base_px, 0u);
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) {
       const uint32_t q = sub_pixel<FLIP, S>(j);
@@ -270,14 +271,16 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     uint32_t f;
     if (cw > 0 && roomy) {
       const int32_t t = kEtcA[cw] - (int32_t)dev_max;
-      if (wave_all(t > 0 && 24 * t * t > sum_sq - r.score)) continue;
+      // (opaque: left alone the optimiser regroups 24 t^2 into (24 t) * t with a quarter-rate v_mul_lo_u32)
+      const int32_t tt = (int32_t)opaque((uint32_t)imad24(t, t, 0));
+      if (wave_all(t > 0 && imad24(tt, 24, 0) > sum_sq - r.score)) continue;
     } else if (cw > 0 && prunable) {
       const uint32_t a2 = (uint32_t)kEtcA[cw] * 0x00010001u;
       const uint32_t up_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_up), dev_rb);
       const uint32_t dn_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_dn), dev_rb);
       const uint32_t ug = umin((uint32_t)kEtcA[cw], room_g_up), dg = umin((uint32_t)kEtcA[cw], room_g_dn);
       const uint32_t up_g = ug - umin(ug, dev_g), dn_g = dg - umin(dg, dev_g);
-      const uint32_t lb_up = udot2_u16(up_rb, up_rb, up_g * up_g), lb_dn = udot2_u16(dn_rb, dn_rb, dn_g * dn_g);
+      const uint32_t lb_up = udot2_u16(up_rb, up_rb, umad24(up_g, up_g, 0u)), lb_dn = udot2_u16(dn_rb, dn_rb, umad24(dn_g, dn_g, 0u));
       if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) continue;
     }
     if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
@@ -493,8 +496,8 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
       const uint32_t l = (qs[0][ch] + qs[2][ch]) >> 3, r = (qs[1][ch] + q3) >> 3;
       const uint32_t t = (qs[0][ch] + qs[1][ch]) >> 3, b = (qs[2][ch] + q3) >> 3;
       const uint32_t dlr = sad_u32(l, r, 0u), dtb = sad_u32(t, b, 0u);
-      e_lr += dlr * dlr;
-      e_tb += dtb * dtb;
+      e_lr = umad24(dlr, dlr, e_lr);
+      e_tb = umad24(dtb, dtb, e_tb);
     }
     flip = !(e_lr > e_tb);
     // The partition differs per lane; instead of evaluating both (or diverging), every lane gathers its 16 pixels

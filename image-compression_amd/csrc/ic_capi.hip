@@ -318,6 +318,7 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
                                       void *d_dst_region, void *hip_stream) {
   if (!d_src || !d_dst_region || n_blocks == 0) return ICAMD_FALSE;
   if (!is_pow2(size) || size < 8) return ICAMD_FALSE;  // pvrtc.cc:640-646
+  if (size >= 65536u) return ICAMD_FALSE;              // as icamd_encode_device: the kernels index pixels with 32 bits
   const uint64_t blocks = (uint64_t)(size / 8) * (size / 4);
   if (!is_pow2(n_blocks) || (first_block & (n_blocks - 1u)) != 0 || (uint64_t)first_block + n_blocks > blocks)
     return fail(ICAMD_ERR_ARG, "PVRTC region must be a power-of-two, aligned range of the image's blocks");

@@ -106,6 +106,7 @@ ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
 }
 ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
 ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
+ICAMD_DEV uint32_t umad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
 ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
@@ -136,6 +137,9 @@ ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_
 // v_mad_i32_i24: a * b + c.  PRECONDITION |a|, |b| < 2^23 (the compiler cannot prove it and would emit
 // v_mul_lo_u32 + v_add_u32 for the plain expression).
 ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+// v_mad_u32_u24: the same for unsigned operands below 2^24 (v_mul_lo_u32, what the plain product compiles to when the
+// range is not provable, issues at a quarter of the rate)
+ICAMD_DEV uint32_t umad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return min(a, b); }
 ICAMD_DEV uint32_t umax(uint32_t a, uint32_t b) { return max(a, b); }
 ICAMD_DEV int32_t imin(int32_t a, int32_t b) { return min(a, b); }

@@ -172,7 +172,7 @@ constexpr uint32_t kLdsDwords = 8 * kMorphLanes * 4;
 template <int kBlocksPerLane, bool DENSE = false>
 __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds) {
   const uint32_t k0 = wg * (kMorphLanes * kBlocksPerLane) + threadIdx.x;
-  const uint32_t n = L.size, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
+  const uint32_t n = L.size, log2_n = L.log2_bw + 3u, bpi_mask = (1u << L.log2_bpi) - 1u, bw_mask = (1u << L.log2_bw) - 1u;
   const uint32_t lane = threadIdx.x & 63u;
   Stash32 stash;
   stash.base = lds + threadIdx.x * 4u;  // [plane][lane][4 dwords]
@@ -190,7 +190,8 @@ __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, 
     const uint32_t by = b >> L.log2_bw, bx = b & bw_mask;
     const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
     if (DENSE) {
-      const uint32_t *row0 = img + (size_t)(by * 4u) * n + bx * 8u + lane * 4u;
+      // n is a power of two <= 32 768 (launch_pvrtc2 refuses more): a pixel's index in its image fits 32 bits, no multiply
+      const uint32_t *row0 = img + (((by * 4u) << log2_n) + bx * 8u + lane * 4u);
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
         const U4 a = load_stream(reinterpret_cast<const U4 *>(row0 + (size_t)y * n));
@@ -199,7 +200,7 @@ __device__ __forceinline__ void pvrtc2_morph(const PvrtcLaunch &L, uint32_t wg, 
         px[8 * y + 4] = c.x; px[8 * y + 5] = c.y; px[8 * y + 6] = c.z; px[8 * y + 7] = c.w;
       }
     } else {
-      load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+      load_block32(img + (((by * 4u) << log2_n) + bx * 8u), n, px);
     }
   };
   auto reduce = [&](uint32_t k, uint32_t px[32]) {
@@ -300,7 +301,7 @@ template <bool EXCHANGE>
 __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds, uint32_t *lds_edge) {
   uint2 *lds_out = reinterpret_cast<uint2 *>(lds);
   const uint32_t k = wg * kEncodeLanes + threadIdx.x;
-  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
+  const uint32_t n = L.size, log2_n = L.log2_bw + 3u, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
   const uint32_t sb = L.log2_strip;
   const uint32_t log2_spi = L.log2_rblocks - sb;  // log2(strips per image (region))
   // consecutive lanes = consecutive block columns of one strip row: a wave reads 2 KiB contiguous per pixel row
@@ -328,7 +329,7 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
         const uint32_t up = (y_in < 2u ? by - 1u : by) & bh_mask, dn = (up + 1u) & bh_mask;
         const uint2 ul = ab[(up << L.log2_bw) + bx], uc = ab[(up << L.log2_bw) + cx];
         const uint2 ll = ab[(dn << L.log2_bw) + bx], lc = ab[(dn << L.log2_bw) + cx];
-        const uint32_t pixel = img[(size_t)((by0 * 4u + r) & (n - 1u)) * n + cx * 8u];
+        const uint32_t pixel = img[(((by0 * 4u + r) & (n - 1u)) << log2_n) + cx * 8u];
         const PvrtcColors c_ul = { ul.x, ul.y }, c_uc = { uc.x, uc.y }, c_ll = { ll.x, ll.y }, c_lc = { lc.x, lc.y };
         reinterpret_cast<uint8_t *>(lds_edge)[w * 32u + r] = (uint8_t)pvrtc_left_edge_mod(pixel, y_in, c_ul, c_uc, c_ll, c_lc);
       }
@@ -344,7 +345,8 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
 
     auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
-      const uint32_t *q = img + (size_t)((by0 * 4u + r) & (n - 1u)) * n;
+      // n = 2^log2_n <= 32 768: the pixel index fits 32 bits -- a shift, not a 64-bit multiply
+      const uint32_t *q = img + (((by0 * 4u + r) & (n - 1u)) << log2_n);
       // (plain loads: the neighbouring lanes' / rows' re-use of these lines wants the cache -- non-temporal was 4 % slower)
       const uint4 v0 = *reinterpret_cast<const uint4 *>(q + bx * 8u), v1 = *reinterpret_cast<const uint4 *>(q + bx * 8u + 4);
       pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
