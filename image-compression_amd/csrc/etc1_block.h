@@ -183,16 +183,17 @@ ICAMD_DEV int32_t eval_codeword_mixed(const uint32_t px[16], const uint32_t abs2
 // bmin / bmax: smallest / largest channel of the decoded base colour (decides, per codeword and for the whole
 // wave at once, whether the unclamped shortcut applies); sub_sum[]: channel sums of the sub-block's 8 pixels;
 // psum[]: 2 (r + g + b) of each of the 16 pixels.
-template <int FLIP, int S, bool TIER>
+template <int FLIP, int S, bool TIER, bool PRUNE>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
                                         const uint32_t bch[3], const uint32_t sub_sum[3]) {
   const uint32_t bsum = bch[0] + bch[1] + bch[2];
   const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;  // the base colour as a pixel dword
   const uint32_t bmin = umin3(bch[0], bch[1], bch[2]), bmax = umax3(bch[0], bch[1], bch[2]);
+  const uint32_t room = umin(bmin, 255u - bmax);  // a modifier m leaves every channel of base +/- m unclamped iff m <= room
   // The modifiers grow with the codeword, so once a codeword clamps somewhere in the wave every later one does too:
   // `fast` is a wave-uniform flag that only ever goes from true to false, and when even codeword 0 clamps (bright /
   // dark / saturated regions) none of the shortcut's per-pixel preparation is executed.
-  bool fast = wave_all(bmin >= (uint32_t)kEtcB[0] && bmax + (uint32_t)kEtcB[0] <= 255u);
+  bool fast = wave_all(room >= (uint32_t)kEtcB[0]);
   // per pixel 2|s| (psum[] holds 2 (r + g + b)) and their sum, shared by all unclamped codewords
   const uint32_t bsum2 = 2u * bsum;
   uint32_t abs2[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, s2 = 0;
@@ -218,14 +219,19 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // keeps the FIRST codeword with the strictly smallest error (etc.cc:401), so nothing it would pick is lost.  Two
   // stages keep the cost off busy content: the L1 deviation (one v_sad_u8 per pixel) decides for the whole wave
   // whether the per-channel deviations are worth computing at all.
-  uint32_t d1 = 0;
-  ICAMD_UNROLL
-  for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
-  // a per-channel deviation is at least a third of the L1 one, and no step exceeds a_7 = 47
-  bool prunable = wave_all(d1 < 3u * (uint32_t)kEtcA[7]);
+  // The instantiation with the mixed tier is only entered by waves of busy blocks (etc1_busy_wave), where this test
+  // practically never passes: it leaves pruning out altogether (a performance choice; pruning never changes a result).
+  bool prunable = false;
+  if (PRUNE) {
+    uint32_t d1 = 0;
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
+    // a per-channel deviation is at least a third of the L1 one, and no step exceeds a_7 = 47
+    prunable = wave_all(d1 < 3u * (uint32_t)kEtcA[7]);
+  }
   // Mixed tier (eval_codeword_mixed) for the codewords the shortcut does not reach: prepared only on busy content --
   // where pruning is on, most of those codewords are skipped anyway.
-  if (TIER && fast && !prunable && !wave_all(bmin >= (uint32_t)kEtcB[7] && bmax + (uint32_t)kEtcB[7] <= 255u)) {
+  if (TIER && fast && !wave_all(room >= (uint32_t)kEtcB[7])) {
     a_fits = true;
     // 32 E0_j + tie field of the a candidate on the pixel's side (3 for s >= 0, 1 for s < 0)
     const int32_t c3 = 3 - 32 * (int32_t)udot4(base_px, base_px, 0u);
@@ -260,7 +266,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     room_g_up = 255u - bch[1];
   }
   // mid-tones everywhere in the wave: no step of any codeword is shortened, the bound is 24 (a_cw - max_c dev_c)^2
-  const bool roomy = prunable && wave_all(bmin >= (uint32_t)kEtcA[7] && bmax + (uint32_t)kEtcA[7] <= 255u);
+  const bool roomy = prunable && wave_all(room >= (uint32_t)kEtcA[7]);
   const uint32_t dev_max = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
   EtcSubResult r;
   r.score = 0; r.cw = 0; r.fields = 0;
@@ -269,7 +275,12 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   for (int cw = 0; cw < 8; ++cw) {
     int32_t s;
     uint32_t f;
-    if (cw > 0 && roomy) {
+    // (r03) the shortcut costs a dozen instructions per codeword -- less than a pruning test -- so only codewords that
+    // would take an exact evaluation are tested
+    if (cw > 0 && fast) fast = wave_all(room >= (uint32_t)kEtcB[cw]);
+    if (fast) {
+      // nothing to prune
+    } else if (cw > 0 && roomy) {
       const int32_t t = kEtcA[cw] - (int32_t)dev_max;
       // (opaque: left alone the optimiser regroups 24 t^2 into (24 t) * t with a quarter-rate v_mul_lo_u32)
       const int32_t tt = (int32_t)opaque((uint32_t)imad24(t, t, 0));
@@ -283,13 +294,12 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       const uint32_t lb_up = udot2_u16(up_rb, up_rb, umad24(up_g, up_g, 0u)), lb_dn = udot2_u16(dn_rb, dn_rb, umad24(dn_g, dn_g, 0u));
       if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) continue;
     }
-    if (cw > 0 && fast) fast = wave_all(bmin >= (uint32_t)kEtcB[cw] && bmax + (uint32_t)kEtcB[cw] <= 255u);
     if (fast) {
       s = eval_codeword_unclamped(abs2, s2, kEtcA[cw], kEtcB[cw]) + e0_sum;
       f = 0u;  // worked out below if this codeword wins
       fast_mask |= 1u << cw;
     } else {
-      if (TIER && a_fits) a_fits = wave_all(bmin >= (uint32_t)kEtcA[cw] && bmax + (uint32_t)kEtcA[cw] <= 255u);
+      if (TIER && a_fits) a_fits = wave_all(room >= (uint32_t)kEtcA[cw]);
       if (TIER && a_fits) {
         s = eval_codeword_mixed<FLIP, S>(px, abs2, k0, base, kEtcA[cw], kEtcB[cw], &f);
       } else {
@@ -302,7 +312,8 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     const bool better = cw == 0 || s > r.score;
     r.score = better ? s : r.score;
     r.cw = better ? (uint32_t)cw : r.cw;
-    r.fields = better ? f : r.fields;
+    // (shortcut codewords come before all others -- `fast` is monotone -- and their fields are worked out below)
+    if (!fast) r.fields = better ? f : r.fields;
   }
   // The winner's index fields in the common format (3 - k per pixel, 2 bits, bits 16..31) when it took the shortcut:
   // high bit = (s >= 0), low bit = (magnitude a chosen) = (2|s| <= 3 (a + b)).  Both are sign bits of one subtraction,
@@ -355,7 +366,7 @@ struct EtcFlipResult {
 };
 
 // FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
-template <int FLIP, bool TIER = false>
+template <int FLIP, bool TIER = false, bool PRUNE = true>
 ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
                                     const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
@@ -395,8 +406,8 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
     r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
     r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
   } else {
-    r0 = search_codewords<FLIP, 0, TIER>(px, psum, e0, b0, s0);
-    r1 = search_codewords<FLIP, 1, TIER>(px, psum, e1, b1, s1);
+    r0 = search_codewords<FLIP, 0, TIER, PRUNE>(px, psum, e0, b0, s0);
+    r1 = search_codewords<FLIP, 1, TIER, PRUNE>(px, psum, e1, b1, s1);
   }
   EtcFlipResult out;
   out.hi = hi | r0.cw << 5 | r1.cw << 2;
@@ -452,7 +463,7 @@ ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
 // TIER: compile the mixed tier (eval_codeword_mixed) into the codeword searches.  It pays on busy content only and its
 // mere presence costs smooth / flat content 3-5 % (r03 A/B), so the kSmallerError kernels carry both instantiations and
 // pick one per wave (etc1_busy_wave).
-template <bool TIER = false>
+template <bool TIER = false, bool PRUNE = true>
 ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
   uint32_t qs[4][3];
@@ -482,10 +493,10 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   EtcFlipResult res;
   bool flip;
   if (strategy == 0u) {  // kSplitHorizontally: top|bottom only
-    res = encode_flip<1, TIER>(px, psum, top, bottom, false);
+    res = encode_flip<1, TIER, PRUNE>(px, psum, top, bottom, false);
     flip = true;
   } else if (strategy == 1u) {  // kSplitVertically: left|right only
-    res = encode_flip<0, TIER>(px, psum, left, right, false);
+    res = encode_flip<0, TIER, PRUNE>(px, psum, left, right, false);
     flip = false;
   } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574: one evaluation, partition chosen per lane
     // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
@@ -520,8 +531,8 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
     res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u);
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
-    const EtcFlipResult r0 = encode_flip<0, TIER>(px, psum, left, right, false);
-    const EtcFlipResult r1 = encode_flip<1, TIER>(px, psum, top, bottom, false);
+    const EtcFlipResult r0 = encode_flip<0, TIER, PRUNE>(px, psum, left, right, false);
+    const EtcFlipResult r1 = encode_flip<1, TIER, PRUNE>(px, psum, top, bottom, false);
     // error_lr <= error_tb  <=>  score_lr >= score_tb  (same Sum|p|^2 on both sides)
     flip = !(r0.score >= r1.score);
     res.hi = flip ? r1.hi : r0.hi;

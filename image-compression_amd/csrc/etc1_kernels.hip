@@ -5,6 +5,13 @@
 #include "ic_launch.h"
 #include "ic_amd.h"
 
+// Calm waves take the instantiation WITHOUT the mixed tier: with it (and pruning) smooth content measured 1.466 -> 1.505 ms
+// and flat 1.35 -> 1.42 ms (r03, profiles/r03_ab_etc1_mixed_tier.log) -- there the tier's register pressure costs more than
+// its arithmetic saves.
+#ifndef ICAMD_ETC1_CALM_TIER
+#define ICAMD_ETC1_CALM_TIER false
+#endif
+
 namespace icamd {
 
 // STRATEGY is a compile-time constant: one kernel per EtcCompressor::CompressionStrategy, so that the straight-line
@@ -19,8 +26,8 @@ __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
   load_tile_block<COMPS>(P, t, px);
   Out8 c;
   if (STRATEGY == 3) c = encode_etc1_block<false>(px, 3u);
-  else if (etc1_busy_wave(px)) c = encode_etc1_block<true>(px, (uint32_t)STRATEGY);  // per wave: with the mixed tier ...
-  else c = encode_etc1_block<false>(px, (uint32_t)STRATEGY);                          // ... or without (smooth / flat content)
+  else if (etc1_busy_wave(px)) c = encode_etc1_block<true, false>(px, (uint32_t)STRATEGY);  // busy wave: mixed tier, no pruning
+  else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true>(px, (uint32_t)STRATEGY);            // calm wave: pruning (+ tier?)
   store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
 }
 

@@ -42,7 +42,10 @@ extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_
         // `strategy` force one of the two for every block (both must produce the reference's bytes on any content)
         const uint32_t st = (uint32_t)strategy & 0xffu;
         const bool tier = (strategy & 0x100) ? true : (strategy & 0x200) ? false : (st != 3u && etc1_busy_wave(px));
-        Out8 c = tier ? encode_etc1_block<true>(px, st) : encode_etc1_block<false>(px, st);
+        // the instantiations the kernels use: <tier, no pruning> for busy waves, <tier, pruning> for calm ones; bit 10
+        // additionally selects the plain <no tier, pruning> form (what the block operations use)
+        Out8 c = (strategy & 0x400) ? encode_etc1_block<false, true>(px, st)
+                 : tier ? encode_etc1_block<true, false>(px, st) : encode_etc1_block<true, true>(px, st);
         memcpy(o, &c, 8);
       }
     }

@@ -353,7 +353,7 @@ def test_etc1_unclamped_shortcut_on_decision_points(emul):
     for comps, strategy in ((3, 2), (3, 0), (3, 1), (4, 2)):
         strip = etc_shortcut_blocks(g, n, comps)
         want = T.oracle_encode(T.ETC1, strip, 4, 4 * n, comps, 0, strategy)
-        for force in (0, 0x100, 0x200):  # per-block choice as in the kernel / mixed tier everywhere / nowhere
+        for force in (0, 0x100, 0x200, 0x400):  # as in the kernel / busy form everywhere / calm form everywhere / plain form
             got = emul_encode(emul, T.ETC1, strip, 4, 4 * n, comps, 0, strategy | force)
             if got != want:
                 bad = [i for i in range(n) if got[i * 8:(i + 1) * 8] != want[i * 8:(i + 1) * 8]]
@@ -363,5 +363,5 @@ def test_etc1_unclamped_shortcut_on_decision_points(emul):
     strip[:, : n] = g.choice(np.array([0, 3, 40, 128, 215, 252, 255], np.uint8), size=(4, n, 3))
     for strategy in (0, 1, 2):
         want = T.oracle_encode(T.ETC1, strip, 4, 4 * n, 3, 0, strategy)
-        for force in (0x100, 0x200):
+        for force in (0x100, 0x200, 0x400):
             assert emul_encode(emul, T.ETC1, strip, 4, 4 * n, 3, 0, strategy | force) == want, (strategy, force)
