@@ -88,3 +88,33 @@ for it in range(20 * n_seeds):
         print("MISMATCH pvrtc decode", n, it)
 print("pvrtc decode soak done, %d mismatches in total, %.1f s" % (bad, time.time() - t0))
 sys.exit(1 if bad else 0)
+
+# r03: the constructed decision-boundary sets of tests/test_kernel_math_host.py (DXT colour index thresholds, ETC1
+# shortcut decision points) through the device kernels, at a size where whole waves take each path
+import test_kernel_math_host as K
+g = np.random.Generator(np.random.PCG64(0xC0DE))
+checked = 0
+for rep in range(max(1, n_seeds // 50)):
+    n = 1 << 17
+    for codec, comps, swap in ((T.DXT1, 3, 0), (T.DXT1, 3, 1), (T.DXT1, 4, 0), (T.DXT5, 4, 0), (T.DXT5, 4, 1)):
+        strip = K.dxt_boundary_blocks(g, n, comps)
+        want = T.oracle_encode(codec, strip, 4, 4 * n, comps, swap, 2, threads=32)
+        out = pkg.encode_device(codec, torch.from_numpy(strip).cuda(), 4, 4 * n, comps, swap_rb=bool(swap))
+        torch.cuda.synchronize()
+        checked += n
+        if out.cpu().numpy().tobytes() != want:
+            bad += 1
+            print("MISMATCH dxt boundary set", codec, comps, swap)
+    for comps, strategy in ((3, 2), (3, 0), (3, 1), (4, 2)):
+        strip = K.etc_shortcut_blocks(g, n, comps)
+        # a block-row strip gives waves of 64 consecutive blocks; also as a 16-row image so that the 16 x 4-block waves mix rows
+        for h, w in ((4, 4 * n), (64, n // 4)):
+            img = np.ascontiguousarray(strip.reshape(4, 16, n // 4, comps).transpose(1, 0, 2, 3).reshape(64, n // 4, comps)) if h == 64 else strip
+            want = T.oracle_encode(T.ETC1, img, h, w, comps, 0, strategy, threads=32)
+            out = pkg.encode_device(T.ETC1, torch.from_numpy(img).cuda(), h, w, comps, etc_strategy=strategy)
+            torch.cuda.synchronize()
+            checked += n
+            if out.cpu().numpy().tobytes() != want:
+                bad += 1
+                print("MISMATCH etc shortcut set", comps, strategy, h, w)
+print("constructed boundary sets on the device: %d blocks, %d mismatches in total, %.1f s" % (checked, bad, time.time() - t0))
