@@ -14,5 +14,5 @@ ab() {  # workload content strategy lib...
 }
 {
 for c in noise smooth flat; do ab etc1_rgb888 $c 2 $LIBS; done
-for st in 0; do ab etc1_rgb888 noise $st $LIBS; done
+for st in 0 3; do ab etc1_rgb888 smooth $st $LIBS; done
 } 2>&1 | tee $O/ab.log

@@ -87,7 +87,6 @@ for it in range(20 * n_seeds):
         bad += 1
         print("MISMATCH pvrtc decode", n, it)
 print("pvrtc decode soak done, %d mismatches in total, %.1f s" % (bad, time.time() - t0))
-sys.exit(1 if bad else 0)
 
 # r03: the constructed decision-boundary sets of tests/test_kernel_math_host.py (DXT colour index thresholds, ETC1
 # shortcut decision points) through the device kernels, at a size where whole waves take each path
@@ -118,3 +117,4 @@ for rep in range(max(1, n_seeds // 50)):
                 bad += 1
                 print("MISMATCH etc shortcut set", comps, strategy, h, w)
 print("constructed boundary sets on the device: %d blocks, %d mismatches in total, %.1f s" % (checked, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
