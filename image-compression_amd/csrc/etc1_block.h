@@ -23,6 +23,15 @@
 
 namespace icamd {
 
+// Diagnostics build only (-DICAMD_ETC1_STATS, never in libic_amd.so as shipped): per-wave counts of which evaluation each
+// codeword of each search took, read back with icamd_debug_etc1_stats (scripts/etc1_path_stats.py).
+#if defined(ICAMD_ETC1_STATS) && !defined(ICAMD_HOST_EMULATION)
+__device__ unsigned int g_etc1_stats[16];
+#define ICAMD_ETC1_COUNT(i) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_etc1_stats[i], 1u); } while (0)
+#else
+#define ICAMD_ETC1_COUNT(i) ((void)0)
+#endif
+
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV uint32_t pk_addsat_u16(uint32_t a, uint32_t b) {
   uint32_t lo = (a & 0xffffu) + (b & 0xffffu), hi = (a >> 16) + (b >> 16);
@@ -268,6 +277,10 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // mid-tones everywhere in the wave: no step of any codeword is shortened, the bound is 24 (a_cw - max_c dev_c)^2
   const bool roomy = prunable && wave_all(room >= (uint32_t)kEtcA[7]);
   const uint32_t dev_max = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
+  ICAMD_ETC1_COUNT(4);
+  if (fast) ICAMD_ETC1_COUNT(5);
+  if (prunable) ICAMD_ETC1_COUNT(6);
+  if (TIER) ICAMD_ETC1_COUNT(7);
   EtcSubResult r;
   r.score = 0; r.cw = 0; r.fields = 0;
   uint32_t fast_mask = 0;  // wave-uniform: bit cw set iff that codeword took the shortcut
@@ -284,7 +297,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       const int32_t t = kEtcA[cw] - (int32_t)dev_max;
       // (opaque: left alone the optimiser regroups 24 t^2 into (24 t) * t with a quarter-rate v_mul_lo_u32)
       const int32_t tt = (int32_t)opaque((uint32_t)imad24(t, t, 0));
-      if (wave_all(t > 0 && imad24(tt, 24, 0) > sum_sq - r.score)) continue;
+      if (wave_all(t > 0 && imad24(tt, 24, 0) > sum_sq - r.score)) { ICAMD_ETC1_COUNT(3); continue; }
     } else if (cw > 0 && prunable) {
       const uint32_t a2 = (uint32_t)kEtcA[cw] * 0x00010001u;
       const uint32_t up_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_up), dev_rb);
@@ -292,19 +305,23 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       const uint32_t ug = umin((uint32_t)kEtcA[cw], room_g_up), dg = umin((uint32_t)kEtcA[cw], room_g_dn);
       const uint32_t up_g = ug - umin(ug, dev_g), dn_g = dg - umin(dg, dev_g);
       const uint32_t lb_up = udot2_u16(up_rb, up_rb, umad24(up_g, up_g, 0u)), lb_dn = udot2_u16(dn_rb, dn_rb, umad24(dn_g, dn_g, 0u));
-      if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) continue;
+      if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) { ICAMD_ETC1_COUNT(3); continue; }
     }
     if (fast) {
+      ICAMD_ETC1_COUNT(0);
       s = eval_codeword_unclamped(abs2, s2, kEtcA[cw], kEtcB[cw]) + e0_sum;
       f = 0u;  // worked out below if this codeword wins
       fast_mask |= 1u << cw;
     } else {
       if (TIER && a_fits) a_fits = wave_all(room >= (uint32_t)kEtcA[cw]);
       if (TIER && a_fits) {
+        ICAMD_ETC1_COUNT(1);
         s = eval_codeword_mixed<FLIP, S>(px, abs2, k0, base, kEtcA[cw], kEtcB[cw], &f);
       } else {
         uint32_t v[4];
         int32_t c[4];
+        ICAMD_ETC1_COUNT(2);
+        ICAMD_ETC1_COUNT(8 + cw);  // which codewords end up in the exact evaluation
         build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
         s = eval_codeword<FLIP, S>(px, v, c, &f);
       }

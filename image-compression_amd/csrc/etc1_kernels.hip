@@ -51,6 +51,18 @@ ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_heuristic_kernel, 4, 3)
 
 }  // extern "C"
 
+#if defined(ICAMD_ETC1_STATS)
+// diagnostics build: read (and optionally clear) the path counters
+extern "C" __attribute__((visibility("default"))) int icamd_debug_etc1_stats(unsigned int *out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_etc1_stats), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned int z[16] = { 0 };
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_etc1_stats), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
 const char *etc1_kernel_name(int comps) { return comps == 4 ? "icamd_etc1_rgba8_kernel" : "icamd_etc1_rgb888_kernel"; }
 
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
