@@ -474,7 +474,10 @@ ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
     lo = umin(lo, t);
     hi = umax(hi, t);
   }
-  return wave_count(hi - lo >= 4u * 141u) >= 48u;
+#ifndef ICAMD_ETC1_BUSY_SPREAD
+#define ICAMD_ETC1_BUSY_SPREAD (4u * 141u)
+#endif
+  return wave_count(hi - lo >= ICAMD_ETC1_BUSY_SPREAD) >= 48u;
 }
 
 // TIER: compile the mixed tier (eval_codeword_mixed) into the codeword searches.  It pays on busy content only and its
