@@ -90,6 +90,9 @@ def parse_args(argv=None):
     ap.add_argument("--precondition-seconds", type=float, default=1.0,
                     help="untimed back-to-back launches of the step before the W warm-up steps, so that the timed K "
                          "steps see the chip's steady power state rather than its ramp out of idle (0 disables)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the torch.distributed / RCCL code path (init, barriers, all-reduce, encode->gather region) "
+                         "even with a single rank")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: debugging only (several ranks sharing one GPU; the gather is staged through the host)")
     args = ap.parse_args(argv)
@@ -492,10 +495,20 @@ def main():
         sys.exit("bench.py: %d ranks but only %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, n_dev))
     device = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(device)
-    distributed = world > 1
+    # --force-distributed: initialise the process group (RCCL) and run the collective paths even with ONE rank -- the only
+    # way to execute them on a 1-GPU box
+    distributed = world > 1 or args.force_distributed
+    if args.force_distributed:
+        os.environ["ICAMD_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:  # only when not launched by torch.distributed.run (single forced rank)
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         import datetime
         tmo = datetime.timedelta(seconds=300)  # a wedged collective fails the run instead of hanging it
         if args.backend == "nccl":

@@ -73,6 +73,13 @@ def pvrtc_region(size, world_size, rank):
             "blocks_h": 1 << (m - m // 2)}
 
 
+def _force_collectives():
+    """ICAMD_FORCE_COLLECTIVES=1: issue the collectives even in a world of one rank -- how the pool's 1-GPU boxes get to
+    execute the RCCL code path at all (communicator set-up, device-tensor gather / all-gather, stream ordering)."""
+    import os
+    return os.environ.get("ICAMD_FORCE_COLLECTIVES") == "1"
+
+
 def _global_rank(group, group_rank):
     """torch.distributed addresses peers (dst= / src=) by GLOBAL rank, even inside a sub-group."""
     if group is None or group is dist.group.WORLD:
@@ -84,7 +91,7 @@ def gather_output(local, world_size, dst=None, group=None):
     """Gathers equally sized per-rank compressed buffers.  dst=None: all-gather (every rank gets
     [world, ...]); dst=r (a rank of `group`): only that rank receives (others get None).  One collective, after the
     encode."""
-    if world_size == 1:
+    if world_size == 1 and not _force_collectives():
         return local.unsqueeze(0)
     if dst is None:
         local = local.contiguous()
@@ -112,7 +119,7 @@ def gather_to_root(local, bufs, counts, rank, dst=0, group=None, host_staged=Fal
     links, every peer writes its own slab of rank 0's HBM).  Unequal counts (n_textures % world != 0): batched
     point-to-point.  host_staged: the gloo debugging path (device tensors staged through host memory)."""
     world = len(counts)
-    if world == 1:
+    if world == 1 and not _force_collectives():
         bufs[0].copy_(local)
         return
     gdst = _global_rank(group, dst)

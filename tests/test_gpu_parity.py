@@ -639,6 +639,27 @@ def test_nccl_sharded_encode_and_gather_on_real_gpus(pkg):
     assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
 
 
+def test_rccl_code_path_executes_with_a_single_rank(pkg):
+    """The pool's boxes have one GPU, so the >= 2-GPU tests above never run there.  RCCL itself works with a world of one
+    rank: this runs the same worker (process-group init on the device, dist.gather / all_gather_into_tensor of device
+    tensors through sharding.gather_to_root / gather_output with the world-size-1 shortcuts switched off) and bench.py's
+    distributed code path (barriers, all-reduces, the double-buffered encode -> gather region on a side stream) over RCCL."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICAMD_FORCE_COLLECTIVES="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29643",
+                        os.path.join(T.ROOT, "tests", "nccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+    d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--steps", "4", "--warmup", "1",
+                    "--workload", "dxt1_rgba8", "--size", "1024", "--batch", "3", "--no-cpu-baseline", "--no-host-api",
+                    "--no-sustained", "--no-single-image", "--precondition-seconds", "0"])
+    assert d["n_gpus"] == 1 and d["parity"].startswith("bit-exact")
+    assert d["value_with_gather"] > 0 and d["gather_ms"] > 0 and d["rank0_copy_matches"] is True
+    assert "backend nccl" in d["gather"]
+
+
 def test_single_process_batch_on_distinct_devices(pkg):
     import torch
     n_dev = torch.cuda.device_count()
