@@ -360,6 +360,16 @@ size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images) {
 
 int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
   if (d_workspace && reinterpret_cast<uintptr_t>(d_workspace) % 8u) return fail(ICAMD_ERR_ARG, "workspace must be 8-byte aligned");
+  if (d_workspace) {
+    // the kernels of this thread's later calls write through this pointer: it must be device memory of the current device
+    hipPointerAttribute_t attr;
+    int dev = -1;
+    if (hipPointerGetAttributes(&attr, d_workspace) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        attr.type != hipMemoryTypeDevice || attr.device != dev) {
+      (void)hipGetLastError();
+      return fail(ICAMD_ERR_ARG, "workspace must be device memory of the current HIP device");
+    }
+  }
   icamd::pvrtc2_set_workspace(d_workspace, bytes);
   return ICAMD_OK;
 }
@@ -953,6 +963,11 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
         void *own = d_dsts ? d_dsts[i] : nullptr;
         void *target = own ? own : (dev == gather_device ? static_cast<void *>(slot) : ((j & 1u) ? st->d_in : st->d_out));
         if (!d_srcs[i]) { local[i] = ICAMD_FALSE; continue; }
+        if (!own && !gather) {  // nowhere to put this image's blocks
+          local[i] = ICAMD_ERR_ARG;
+          if (errors[(size_t)d].empty()) errors[(size_t)d] = "icamd_encode_batch_sharded_device: image without an output buffer";
+          continue;
+        }
         local[i] = icamd_encode_device(codec, etc_strategy, src_components, swap_rb, height, width, height, width,
                                        row_stride_bytes, 1, 0, 0, d_srcs[i], target, s);
         if (local[i] == ICAMD_OK && gather && target != slot) {

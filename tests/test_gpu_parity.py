@@ -850,6 +850,10 @@ def test_sharded_device_batch_one_gpu_listed_several_times(pkg):
                                         gathered=torch.zeros((1, 2048), dtype=torch.uint8, device="cuda"))
     st, _, _ = pkg.encode_batch_sharded_device(pkg.PVRTC2, [src], 48, 48, 4, [0], gather_device=0)
     assert st == [pkg.FALSE]
+    # an image with neither its own output buffer nor a gather slot is an argument error of that image only
+    good = torch.zeros(pkg.encoded_size(pkg.DXT1, 64, 64), dtype=torch.uint8, device="cuda")
+    with pytest.raises(pkg.BackendError):
+        pkg.encode_batch_sharded_device(pkg.DXT1, [src, src], 64, 64, 4, [0], outs=[good, None])
 
 
 def test_sharded_device_batch_on_distinct_gpus(pkg):
@@ -859,6 +863,13 @@ def test_sharded_device_batch_on_distinct_gpus(pkg):
     devices = list(range(torch.cuda.device_count()))
     _sharded_case(pkg, pkg.DXT1, 4, 512, 2 * len(devices) + 1, devices)
     _sharded_case(pkg, pkg.ETC1, 3, 256, len(devices) + 1, devices)
+
+
+def test_pvrtc_workspace_must_be_device_memory(pkg):
+    import numpy as np
+    host = np.zeros(4096, np.uint8)
+    assert pkg.lib().icamd_pvrtc2_set_workspace(pkg.ctypes.c_void_p(host.ctypes.data), host.size) == -4  # ICAMD_ERR_ARG
+    assert pkg.pvrtc_set_workspace(None)
 
 
 def test_clock_probe_reports_a_plausible_shader_clock(pkg):
