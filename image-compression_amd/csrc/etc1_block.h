@@ -466,6 +466,10 @@ ICAMD_DEV uint32_t assemble_indices(uint32_t f0, uint32_t f1, bool flip) {
 // tier what its exact evaluations want.  The instantiation with the tier runs ~5 % slower wherever the tier is not used
 // (register pressure), so a wave of mostly calm blocks takes the one without.  Only a performance choice: both produce
 // the same bytes.
+// (threshold sweep 564 / 200 / 100 / 50: profiles/r03_ab_etc1_mixed_tier.log, P)
+#ifndef ICAMD_ETC1_BUSY_SPREAD
+#define ICAMD_ETC1_BUSY_SPREAD (4u * 141u)
+#endif
 ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
   uint32_t lo = 0xffffffffu, hi = 0u;
   ICAMD_UNROLL
@@ -474,9 +478,6 @@ ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
     lo = umin(lo, t);
     hi = umax(hi, t);
   }
-#ifndef ICAMD_ETC1_BUSY_SPREAD
-#define ICAMD_ETC1_BUSY_SPREAD (4u * 141u)
-#endif
   return wave_count(hi - lo >= ICAMD_ETC1_BUSY_SPREAD) >= 48u;
 }
 
