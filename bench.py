@@ -555,18 +555,20 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # ONE event between consecutive steps (K + 1 in all): a step's duration is the distance between its event and the
+    # next one, i.e. its kernel(s) plus the sub-microsecond dispatch gap.  (An event PAIR around every launch, as r01 / r02
+    # had it, puts two timestamp packets between any two kernels and costs the timed region ~5 us per step.)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record(stream)
+        marks[i].record(stream)
         step(outs[0])
-        ends[i].record(stream)
+    marks[args.steps].record(stream)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    kernel_ms = marks[0].elapsed_time(marks[args.steps]) / args.steps
 
     def max_over_ranks(x):
         if not distributed:
