@@ -297,8 +297,18 @@ constexpr uint32_t kStageSlots = (kEncodeLanes / 8) * 66;  // sb = 3: 32 chunks 
 // right of ITS strip (4 << log2_strip pixel rows) are computed up front by the workgroup, one pixel per lane
 // (pvrtc_left_edge_mod), parked in 128 bytes of LDS, and the single barrier of the kernel follows -- before the strips
 // start, where it costs nothing.  -9 % executed instructions per block (r03).
-template <bool EXCHANGE>
-__device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds, uint32_t *lds_edge) {
+// DMA (with EXCHANGE): the strip's pixel rows are fetched by LDS-DMA (global_load_lds_dwordx4, no destination VGPRs) into a
+// per-wave ring of kRowRing row slots, three rows ahead of their use -- three times the bytes in flight of the register
+// path, whose depth the 168-VGPR budget caps at one row (profiles/r03_ab_pvrtc_prefetch.log: 15 % of the kernel is HBM
+// latency).  A row slot is [half][lane][4 pixels] (2 KiB), read back by its lane with two conflict-free ds_read_b128.
+// The waits are counted by hand (s_waitcnt vmcnt(4): everything but the two youngest rows has landed) and the reads are
+// inline asm, because hipcc drains ALL outstanding loads (vmcnt(0)) before any LDS read it can see while a DMA is in flight.
+constexpr uint32_t kRowRing = 4;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+template <bool EXCHANGE, bool DMA = false>
+__device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg, uint32_t *lds, uint32_t *lds_edge,
+                                              uint32_t *lds_rows = nullptr) {
   uint2 *lds_out = reinterpret_cast<uint2 *>(lds);
   const uint32_t k = wg * kEncodeLanes + threadIdx.x;
   const uint32_t n = L.size, log2_n = L.log2_bw + 3u, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
@@ -344,7 +354,32 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
     const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
 
+    // DMA: this wave's ring (all 64 lanes of a wave share the strip row and the image when the region is >= 64 columns wide)
+    lds_u32 *ring = DMA ? (lds_u32 *)(lds_rows + (threadIdx.x >> 6) * (kRowRing * 512u)) : nullptr;
+    const uint32_t ring_lane_byte = DMA ? (uint32_t)(uintptr_t)ring + (threadIdx.x & 63u) * 16u : 0u;
+    auto dma_row = [&](uint32_t r) {  // pixel row r of the strip -> slot r % kRowRing; rows past the strip wrap like the reads do
+      const uint32_t *q = img + ((((by0 * 4u + r) & (n - 1u)) << log2_n) + bx * 8u);
+      lds_u32 *slot = ring + (r & (kRowRing - 1u)) * 512u;
+      __builtin_amdgcn_global_load_lds(q, slot, 16, 0, 0);             // lane l: its first four pixels -> slot + 16 l
+      __builtin_amdgcn_global_load_lds(q + 4, slot + 256, 16, 0, 0);   // ... its last four -> slot + 1024 + 16 l
+    };
+    if (DMA) {
+#pragma unroll
+      for (uint32_t r = 0; r + 1 < kRowRing; ++r) dma_row(r);
+    }
     auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
+      if (DMA) {
+        // rows r + 1 and r + 2 (four DMA instructions) may still be in flight; row r and everything older has landed
+        uint4 v0, v1;
+        const uint32_t addr = ring_lane_byte + (r & (kRowRing - 1u)) * 2048u;
+        asm volatile("s_waitcnt vmcnt(4)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1) : "v"(addr) : "memory");
+        pixels[0] = v0.x; pixels[1] = v0.y; pixels[2] = v0.z; pixels[3] = v0.w;
+        pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
+        // the slot of row r - 1 (read one call ago, its ds_reads long complete) takes row r + 3
+        dma_row(r + kRowRing - 1u);
+        return;
+      }
       // n = 2^log2_n <= 32 768: the pixel index fits 32 bits -- a shift, not a 64-bit multiply
       const uint32_t *q = img + (((by0 * 4u + r) & (n - 1u)) << log2_n);
       // (plain loads: the neighbouring lanes' / rows' re-use of these lines wants the cache -- non-temporal was 4 % slower)
@@ -353,8 +388,23 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
       pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
       if (!EXCHANGE) *right_px = q[xr * 8u];
     };
+    PvrtcColors *requested = nullptr;  // DMA: the colour row whose loads hipcc does not know about
     auto load_colours = [&](int j, PvrtcColors c[3]) {
       const uint2 *row = ab + (((by0 + (uint32_t)j) & bh_mask) << L.log2_bw);
+      if (DMA) {
+        // Loads hipcc does not know about, so that it does not drain the row ring (vmcnt(0)) where their results are used:
+        // colour row j >= 2 is requested a whole block (four load_px calls, eight younger DMA instructions) before its
+        // first use, so the vmcnt(4) of those calls has retired it; rows -1, 0 and 1 are used sooner and are waited for here.
+        uint2 l, m, r;
+        asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %4, off\n\tglobal_load_dwordx2 %2, %5, off"
+                     : "=&v"(l), "=&v"(m), "=&v"(r) : "v"(row + xl), "v"(row + bx), "v"(row + xr) : "memory");
+        if (j <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        requested = c;
+        c[0].a = l.x; c[0].b = l.y;
+        c[1].a = m.x; c[1].b = m.y;
+        c[2].a = r.x; c[2].b = r.y;
+        return;
+      }
       const uint2 l = row[xl], m = row[bx], r = row[xr];
       c[0].a = l.x; c[0].b = l.y;
       c[1].a = m.x; c[1].b = m.y;
@@ -366,6 +416,17 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     uint2 *slot0 = lds_out + (threadIdx.x >> sb) * chunk_slots + (spread_bits16(threadIdx.x & sub) << 1);
     auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
       const uint2 v = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
+      if (DMA) {  // (stores hipcc can see are merged into one flat store, which drains the row ring)
+        // A block is stored after the third load_px of its walk step, whose vmcnt(4) has retired the colour loads issued
+        // at the top of the step: from here on their results may be used, and no use can be scheduled before this point.
+        asm volatile("" : "+v"(requested[0].a), "+v"(requested[0].b), "+v"(requested[1].a), "+v"(requested[1].b),
+                          "+v"(requested[2].a), "+v"(requested[2].b));
+        if (L.stage_stores)
+          asm volatile("ds_write_b64 %0, %1" :: "v"((uint32_t)(uintptr_t)(lds_u32 *)(uint32_t *)(slot0 + spread_bits16(j))), "v"(v) : "memory");
+        else
+          asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + ((zx | spread_bits16(by0 + j)) - L.z_first)), "v"(v) : "memory");
+        return;
+      }
       if (L.stage_stores) slot0[spread_bits16(j)] = v;
       else dst[(zx | spread_bits16(by0 + j)) - L.z_first] = v;
     };
@@ -374,6 +435,11 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     const bool wave_end = (threadIdx.x & 63u) == 63u;
     auto right_of = [&](uint32_t j, uint32_t col0) -> uint32_t {
       const uint32_t from_lane = (uint32_t)__shfl_down((int)col0, 1);
+      if (DMA) {  // an LDS read hipcc can see would drain the row ring (vmcnt(0)); the edge values were written before the barrier
+        uint32_t e;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"((uint32_t)(uintptr_t)(lds_u32 *)(edge_row + j)) : "memory");
+        return wave_end ? e : from_lane;
+      }
       return wave_end ? edge_row[j] : from_lane;
     };
     pvrtc_encode_strip<EXCHANGE>(1u << sb, load_px, load_colours, store, right_of);
@@ -403,7 +469,12 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
 extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_kernel(PvrtcLaunch L) {
   __shared__ uint32_t lds[kStageSlots * 2];
   __shared__ uint32_t lds_edge[4 * 8];  // per wave: 32 bytes = the values right of its last lane's strip
+#if !defined(ICAMD_PVRTC_NO_ROW_DMA)  // (the register-path build, for A/B runs: -DICAMD_PVRTC_NO_ROW_DMA)
+  __shared__ __attribute__((aligned(16))) uint32_t lds_rows[4 * kRowRing * 512];  // per wave: kRowRing row slots of 2 KiB
+  pvrtc2_encode<true, true>(L, blockIdx.x, lds, lds_edge, lds_rows);
+#else
   pvrtc2_encode<true>(L, blockIdx.x, lds, lds_edge);
+#endif
 }
 // regions fewer than 64 block columns wide (textures below 512^2): a wave holds several strip rows, every lane computes
 // the values right of its blocks itself
