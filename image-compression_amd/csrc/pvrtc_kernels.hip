@@ -357,8 +357,11 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     // DMA: this wave's ring (all 64 lanes of a wave share the strip row and the image when the region is >= 64 columns wide)
     lds_u32 *ring = DMA ? (lds_u32 *)(lds_rows + (threadIdx.x >> 6) * (kRowRing * 512u)) : nullptr;
     const uint32_t ring_lane_byte = DMA ? (uint32_t)(uintptr_t)ring + (threadIdx.x & 63u) * 16u : 0u;
-    auto dma_row = [&](uint32_t r) {  // pixel row r of the strip -> slot r % kRowRing; rows past the strip wrap like the reads do
-      const uint32_t *q = img + ((((by0 * 4u + r) & (n - 1u)) << log2_n) + bx * 8u);
+    // pixel row r of the strip -> slot r % kRowRing.  The walk ends at row 4 K (the first row below the strip); the three
+    // requests past it keep the wait counts uniform but re-fetch row 4 K (an L2 hit) instead of 3 / 32 more HBM bytes.
+    const uint32_t last_row = 4u << sb;
+    auto dma_row = [&](uint32_t r) {
+      const uint32_t *q = img + ((((by0 * 4u + (r < last_row ? r : last_row)) & (n - 1u)) << log2_n) + bx * 8u);
       lds_u32 *slot = ring + (r & (kRowRing - 1u)) * 512u;
       __builtin_amdgcn_global_load_lds(q, slot, 16, 0, 0);             // lane l: its first four pixels -> slot + 16 l
       __builtin_amdgcn_global_load_lds(q + 4, slot + 256, 16, 0, 0);   // ... its last four -> slot + 1024 + 16 l
@@ -471,7 +474,12 @@ extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_k
   __shared__ uint32_t lds_edge[4 * 8];  // per wave: 32 bytes = the values right of its last lane's strip
 #if !defined(ICAMD_PVRTC_NO_ROW_DMA)  // (the register-path build, for A/B runs: -DICAMD_PVRTC_NO_ROW_DMA)
   __shared__ __attribute__((aligned(16))) uint32_t lds_rows[4 * kRowRing * 512];  // per wave: kRowRing row slots of 2 KiB
+#if defined(ICAMD_PVRTC_XCD_REMAP)
+  const uint32_t nwg = gridDim.x, wg = (nwg & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3);
+  pvrtc2_encode<true, true>(L, wg, lds, lds_edge, lds_rows);
+#else
   pvrtc2_encode<true, true>(L, blockIdx.x, lds, lds_edge, lds_rows);
+#endif
 #else
   pvrtc2_encode<true>(L, blockIdx.x, lds, lds_edge);
 #endif
