@@ -40,7 +40,9 @@ EXPORTS = [
     "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
+    "icamd_container_size", "icamd_container_write",
 ]
+CONTAINER_DDS, CONTAINER_KTX, CONTAINER_PKM, CONTAINER_PVR = 0, 1, 2, 3
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
 _lib = None
@@ -72,6 +74,10 @@ def lib():
         L.icamd_compress_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _vp, _sz, _vp]
         L.icamd_compress_and_pad_device.restype = _ci
         L.icamd_compress_and_pad_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _sz, _vp]
+        L.icamd_container_size.restype = _sz
+        L.icamd_container_size.argtypes = [_ci, _ci, _u32, _u32, _u32]
+        L.icamd_container_write.restype = _ci
+        L.icamd_container_write.argtypes = [_ci, _ci, _u32, _u32, _u32, _vp, _vp, _vp, _sz]
         L.icamd_encode_device.restype = _ci
         L.icamd_encode_device.argtypes = [_ci, _ci, _ci, _ci, _u32, _u32, _u32, _u32, _u32, _u32, _sz, _sz, _vp, _vp, _vp]
         L.icamd_decode_device.restype = _ci
@@ -372,6 +378,24 @@ def create_solid_host(compressor, fmt, height, width, color):
     out = np.zeros(max(n, 1), np.uint8)
     st = lib().icamd_create_solid(compressor, fmt, height, width, buf, out.ctypes.data, n)
     return out[:n].tobytes() if _check(st, "icamd_create_solid") else None
+
+
+def container_size(container, codec, height, width, levels=1):
+    return int(lib().icamd_container_size(container, codec, height, width, levels))
+
+
+def container_write(container, codec, height, width, levels_data):
+    """Frames the block streams of the mip levels (largest first, bytes-like each) as a DDS / KTX / PKM / PVR file image
+    (extension, include/ic_amd.h: the reference has no container code); bytes, or None where the C side says false."""
+    import numpy as np
+    levels = [np.frombuffer(bytes(b), np.uint8) for b in levels_data]
+    n = len(levels)
+    total = container_size(container, codec, height, width, n)
+    out = np.zeros(max(total, 1), np.uint8)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[ctypes.c_void_p(a.ctypes.data if a.size else 0) for a in levels])
+    sizes = (ctypes.c_size_t * max(n, 1))(*[a.size for a in levels])
+    st = lib().icamd_container_write(container, codec, height, width, n, ptrs, sizes, out.ctypes.data, total)
+    return out[:total].tobytes() if _check(st, "icamd_container_write") else None
 
 
 def copy_subimage_device(compressor, fmt, blocks, compressed_height, compressed_width, start_row, start_column, height,

@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "containers.h"
 #include "ic_launch.h"
 
 namespace {
@@ -994,6 +995,45 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
     for (const std::string &e : errors)
       if (!e.empty()) { g_last_error = e; break; }
   return first;
+}
+
+// ---- container framing (extension; csrc/containers.h) ----
+size_t icamd_container_size(int container, int codec, uint32_t height, uint32_t width, uint32_t levels) {
+  using namespace icamd;
+  if (!container_supports(container, codec) || height == 0 || width == 0 || levels == 0 || levels > 32) return 0;
+  if (container == ICAMD_CONTAINER_PKM && (levels != 1 || height > 65532u || width > 65532u)) return 0;
+  if (codec == ICAMD_PVRTC2 && (height != width || !is_pow2(width))) return 0;
+  size_t total = container_header_size(container);
+  for (uint32_t l = 0; l < levels; ++l) {
+    if (l > 0 && (height >> l) == 0 && (width >> l) == 0) return 0;  // past the 1 x 1 level
+    const size_t b = container_level_bytes(codec, height, width, l);
+    if (b == 0 || b > 0xffffffffull) return 0;
+    total += container_level_prefix(container) + b;
+  }
+  return total;
+}
+
+int icamd_container_write(int container, int codec, uint32_t height, uint32_t width, uint32_t levels,
+                          const uint8_t *const *level_data, const size_t *level_sizes, uint8_t *out, size_t out_size) {
+  using namespace icamd;
+  if (container < ICAMD_CONTAINER_DDS || container > ICAMD_CONTAINER_PVR) return fail(ICAMD_ERR_ARG, "unknown container");
+  if (codec < ICAMD_DXT1 || codec > ICAMD_PVRTC2) return fail(ICAMD_ERR_ARG, "unknown codec");
+  if (!level_data || !level_sizes || !out) return ICAMD_FALSE;
+  const size_t need = icamd_container_size(container, codec, height, width, levels);
+  if (need == 0 || out_size != need) return ICAMD_FALSE;
+  for (uint32_t l = 0; l < levels; ++l)
+    if (!level_data[l] || level_sizes[l] != container_level_bytes(codec, height, width, l)) return ICAMD_FALSE;
+  container_write_header(container, codec, height, width, levels, level_sizes[0], out);
+  uint8_t *p = out + container_header_size(container);
+  for (uint32_t l = 0; l < levels; ++l) {
+    if (container_level_prefix(container)) {
+      put_le32(p, (uint32_t)level_sizes[l]);  // KTX imageSize; block streams are multiples of 8 bytes: no mip padding
+      p += 4;
+    }
+    std::memcpy(p, level_data[l], level_sizes[l]);
+    p += level_sizes[l];
+  }
+  return ICAMD_OK;
 }
 
 #pragma GCC visibility pop

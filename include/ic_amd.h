@@ -240,6 +240,20 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
                                       int gather_device, void *d_gathered, size_t gathered_image_stride_bytes,
                                       int *statuses);
 
+/* ---- container framing (EXTENSION: SURVEY.md 8(f) row 4, tail) ----
+ * The reference ends at the raw block stream (compressed_image.h:52-66); it has no file-container code, so there is
+ * nothing to pin these against.  Host-side byte framing only (no device work), layouts from the public format
+ * descriptions (csrc/containers.h): DDS (DXT1 / DXT5), KTX 1.1 and PVR v3 (all four codecs), PKM (ETC1, one level).
+ * Level l of a height x width texture is max(1, height >> l) x max(1, width >> l) pixels, its bytes exactly what
+ * icamd_compress / icamd_downsample return for that size (PVRTC: square power-of-two levels of 8 x 8 and up only). */
+enum { ICAMD_CONTAINER_DDS = 0, ICAMD_CONTAINER_KTX = 1, ICAMD_CONTAINER_PKM = 2, ICAMD_CONTAINER_PVR = 3 };
+/* File size for `levels` mip levels (>= 1); 0 if the container cannot hold that codec / size / level count. */
+size_t icamd_container_size(int container, int codec, uint32_t height, uint32_t width, uint32_t levels);
+/* Writes header + levels (largest first) into out[out_size]; out_size must equal icamd_container_size(...) and
+ * level_sizes[l] the level's block-stream size, else ICAMD_FALSE.  ICAMD_ERR_ARG for an unknown container / codec. */
+int icamd_container_write(int container, int codec, uint32_t height, uint32_t width, uint32_t levels,
+                          const uint8_t *const *level_data, const size_t *level_sizes, uint8_t *out, size_t out_size);
+
 /* ---- runtime ---- */
 int icamd_device_count(void);             /* HIP devices visible; 0 if none */
 const char *icamd_last_error(void);       /* thread-local message for the last negative status */

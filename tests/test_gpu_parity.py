@@ -382,6 +382,40 @@ def test_blockops_match_oracle(pkg):
     assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)
 
 
+def test_mip_chain_in_containers(pkg):
+    """8(f) row 4 tail: a device-encoded texture and its compressed-domain mip chain framed as KTX / DDS / PVR; the levels
+    read back out of the file image are the oracle's levels (the framing itself is pinned in tests/test_containers.py)."""
+    import struct
+    for codec, compressor, fmt, container in [(0, T.DXTC, T.RGB, pkg.CONTAINER_DDS), (1, T.DXTC, T.RGBA, pkg.CONTAINER_KTX),
+                                             (2, T.ETC, T.RGB, pkg.CONTAINER_PVR)]:
+        n = 256
+        img = T.s_smooth(n, n, T.comps_of(fmt), index=11)
+        levels = [pkg.compress_host(compressor, fmt, img, n, n)]
+        want = [T.oracle_compress(compressor, fmt, img, n, n)]
+        while n > 4:  # Downsample needs at least a 2 x 2 block grid (compressor4x4_helper.h:594-636)
+            levels.append(pkg.downsample_host(compressor, fmt, levels[-1], n, n))
+            want.append(T.oracle_downsample(compressor, fmt, want[-1], n, n))
+            n //= 2
+        blob = pkg.container_write(container, codec, 256, 256, levels)
+        assert blob is not None and len(blob) == pkg.container_size(container, codec, 256, 256, len(levels))
+        off = {pkg.CONTAINER_DDS: 128, pkg.CONTAINER_KTX: 64, pkg.CONTAINER_PVR: 52}[container]
+        for lvl in want:
+            if container == pkg.CONTAINER_KTX:
+                assert struct.unpack_from("<I", blob, off)[0] == len(lvl)
+                off += 4
+            assert blob[off:off + len(lvl)] == lvl
+            off += len(lvl)
+        assert off == len(blob)
+    # PKM: one ETC1 level of a ragged size
+    img = T.s_mixed(61, 59, 3, index=5)
+    blob = pkg.container_write(pkg.CONTAINER_PKM, 2, 61, 59, [pkg.compress_host(T.ETC, T.RGB, img, 61, 59)])
+    assert blob[:6] == b"PKM 10" and blob[16:] == T.oracle_compress(T.ETC, T.RGB, img, 61, 59)
+    # PVR: a PVRTC texture (Z-order block stream as the encoder emits it)
+    img = T.s_smooth(64, 64, 4, index=6)
+    blob = pkg.container_write(pkg.CONTAINER_PVR, 3, 64, 64, [pkg.compress_host(T.PVRTC, T.RGBA, img, 64, 64)])
+    assert blob[52:] == T.oracle_compress(T.PVRTC, T.RGBA, img, 64, 64)
+
+
 def test_single_process_multi_device_batch(pkg):
     # icamd_compress_batch: one worker thread, stream and staging set per device-list entry.  The GPU box has one
     # GPU, so device 0 is listed several times, which exercises the same concurrency as several devices would.
