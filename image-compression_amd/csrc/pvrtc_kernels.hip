@@ -474,10 +474,6 @@ extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_k
   __shared__ uint32_t lds_edge[4 * 8];  // per wave: 32 bytes = the values right of its last lane's strip
 #if !defined(ICAMD_PVRTC_NO_ROW_DMA)  // (the register-path build, for A/B runs: -DICAMD_PVRTC_NO_ROW_DMA)
   __shared__ __attribute__((aligned(16))) uint32_t lds_rows[4 * kRowRing * 512];  // per wave: kRowRing row slots of 2 KiB
-#if defined(ICAMD_PVRTC_LDS_PAD)  // occupancy experiment: 2 workgroups per CU
-  __shared__ uint32_t lds_pad[7000];
-  if (L.total_strips == 0xffffffffu) lds_pad[threadIdx.x] = 1, lds[0] = lds_pad[threadIdx.x ^ 1];
-#endif
 #if defined(ICAMD_PVRTC_XCD_REMAP)
   const uint32_t nwg = gridDim.x, wg = (nwg & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (nwg >> 3) + (blockIdx.x >> 3);
   pvrtc2_encode<true, true>(L, wg, lds, lds_edge, lds_rows);
