@@ -947,6 +947,13 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
         errors[(size_t)d] = what;
       };
       if (hipSetDevice(dev) != hipSuccess) return fail_all(ICAMD_ERR_HIP, "hipSetDevice failed");
+      if (gather && dev != gather_device) {
+        // direct xGMI copies into the gather buffer: without peer access hipMemcpyPeerAsync bounces through host memory.
+        // Best effort -- "already enabled" and "not supported" both leave a working (if slower) copy path.
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, gather_device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(gather_device, 0);
+        (void)hipGetLastError();
+      }
       std::unique_ptr<Staging> st = pool_take(dev);
       // images without an output buffer of their own (gather only) are encoded into one of two scratch buffers, so
       // that the peer copy of image j overlaps the encode of image j + 1 (two streams, alternating)

@@ -37,7 +37,10 @@ namespace {
 
 constexpr int kMorphLanes = 256;
 constexpr int kEncodeLanes = 256;
-constexpr uint32_t kFullChipLanes = 256u * 4u * 64u * 2u;  // two waves on each of the 1 024 SIMDs
+#ifndef ICAMD_PVRTC_FULL_CHIP_WAVES
+#define ICAMD_PVRTC_FULL_CHIP_WAVES 2u
+#endif
+constexpr uint32_t kFullChipLanes = 256u * 4u * 64u * ICAMD_PVRTC_FULL_CHIP_WAVES;  // two waves on each of the 1 024 SIMDs
 
 __device__ __forceinline__ void load_block32(const uint32_t *p, uint32_t n, uint32_t px[32]) {
 #pragma unroll
