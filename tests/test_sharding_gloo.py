@@ -1,6 +1,7 @@
 """N>1 path on CPU: world_size-2 `gloo` process group.  The sharding / gather logic of
 image-compression_amd/sharding.py is exercised with the ORACLE standing in for the device encoder (tests only);
 the assembled result must equal the oracle's output for the whole batch / whole image."""
+import pytest
 import os
 import socket
 
@@ -110,13 +111,13 @@ def _worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-def test_sharded_encode_and_gather_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])  # 3: unequal texture counts and slab heights on the ranks
+def test_sharded_encode_and_gather(world):
     port = _free_port()
     with mp.Manager() as mgr:
         results = mgr.dict()
         mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
-        assert dict(results) == {0: 1, 1: 1}
+        assert dict(results) == {r: 1 for r in range(world)}
 
 
 def test_ranges_partition_exactly():
