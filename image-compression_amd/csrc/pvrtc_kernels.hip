@@ -611,7 +611,9 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
       return Q;
     };
     const PvrtcLaunch Q = part(0, count, L.log2_strip);
-    const bool small = Q.total_blocks < (uint32_t)kMorphBlocksPerLane * kFullChipLanes;
+    // one block per lane up to AND INCLUDING two waves per SIMD of four-block lanes -- one 4096^2 texture is exactly that:
+    // morph 17.0 -> 14.7 us per call (r03, rocprofv3; the memory-bound kernel wants the extra waves in flight)
+    const bool small = Q.total_blocks <= (uint32_t)kMorphBlocksPerLane * kFullChipLanes;
     const uint32_t per_wg = kMorphLanes * (small ? 1 : kMorphBlocksPerLane);
     const dim3 gm((Q.total_blocks + per_wg - 1) / per_wg), ge((Q.total_strips + kEncodeLanes - 1) / kEncodeLanes);
     if (small) hipLaunchKernelGGL(icamd_pvrtc2_morph_small_kernel, gm, dim3(kMorphLanes), 0, stream, Q);

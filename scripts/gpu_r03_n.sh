@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 WL=${WL:-pvrtc2_rgba8}
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/single_$WL -o x -- python bench.py --steps 20 --warmup 5 --workload $WL --no-cpu-baseline --no-host-api --no-sustained --no-verify > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/single_$WL -o x -- env ICAMD_ALLOW_LIB_OVERRIDE=1 ICAMD_LIB_PATH=$PWD/${LIB:-image-compression_amd/libic_amd.so} python bench.py --steps 20 --warmup 5 --workload $WL --no-cpu-baseline --no-host-api --no-sustained --no-verify > /dev/null 2>&1
 python - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(list)
