@@ -192,9 +192,15 @@ ICAMD_DEV int32_t eval_codeword_mixed(const uint32_t px[16], const uint32_t abs2
 // bmin / bmax: smallest / largest channel of the decoded base colour (decides, per codeword and for the whole
 // wave at once, whether the unclamped shortcut applies); sub_sum[]: channel sums of the sub-block's 8 pixels;
 // psum[]: 2 (r + g + b) of each of the 16 pixels.
-template <int FLIP, int S, bool TIER, bool PRUNE>
+// skip: this lane's result will not be used (a one-colour block inside a mixed wave, encoded by
+// encode_etc1_constant_block instead) -- it takes no part in the wave-uniform decisions below, so a lane that would
+// veto the shortcut, the tier or a pruning step for everyone (a saturated flat colour, typically) no longer does.
+// (SKIP is a template parameter so that waves without such lanes run exactly the code they ran before: r03 A/B, a run-time
+// flag alone cost noise content 5 %.)
+template <int FLIP, int S, bool TIER, bool PRUNE, bool SKIP = false>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
-                                        const uint32_t bch[3], const uint32_t sub_sum[3]) {
+                                        const uint32_t bch[3], const uint32_t sub_sum[3], bool skip_lane = false) {
+  const bool skip = SKIP && skip_lane;
   const uint32_t bsum = bch[0] + bch[1] + bch[2];
   const uint32_t base_px = bch[0] | bch[1] << 8 | bch[2] << 16;  // the base colour as a pixel dword
   const uint32_t bmin = umin3(bch[0], bch[1], bch[2]), bmax = umax3(bch[0], bch[1], bch[2]);
@@ -202,7 +208,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // The modifiers grow with the codeword, so once a codeword clamps somewhere in the wave every later one does too:
   // `fast` is a wave-uniform flag that only ever goes from true to false, and when even codeword 0 clamps (bright /
   // dark / saturated regions) none of the shortcut's per-pixel preparation is executed.
-  bool fast = wave_all(room >= (uint32_t)kEtcB[0]);
+  bool fast = wave_all(skip || room >= (uint32_t)kEtcB[0]);
   // per pixel 2|s| (psum[] holds 2 (r + g + b)) and their sum, shared by all unclamped codewords
   const uint32_t bsum2 = 2u * bsum;
   uint32_t abs2[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, s2 = 0;
@@ -236,11 +242,11 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) d1 = umax(d1, sad_u8(px[sub_pixel<FLIP, S>(j)] & 0x00ffffffu, base_px, 0u));
     // a per-channel deviation is at least a third of the L1 one, and no step exceeds a_7 = 47
-    prunable = wave_all(d1 < 3u * (uint32_t)kEtcA[7]);
+    prunable = wave_all(skip || d1 < 3u * (uint32_t)kEtcA[7]);
   }
   // Mixed tier (eval_codeword_mixed) for the codewords the shortcut does not reach: prepared only on busy content --
   // where pruning is on, most of those codewords are skipped anyway.
-  if (TIER && fast && !wave_all(room >= (uint32_t)kEtcB[7])) {
+  if (TIER && fast && !wave_all(skip || room >= (uint32_t)kEtcB[7])) {
     a_fits = true;
     // 32 E0_j + tie field of the a candidate on the pixel's side (3 for s >= 0, 1 for s < 0)
     const int32_t c3 = 3 - 32 * (int32_t)udot4(base_px, base_px, 0u);
@@ -275,7 +281,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     room_g_up = 255u - bch[1];
   }
   // mid-tones everywhere in the wave: no step of any codeword is shortened, the bound is 24 (a_cw - max_c dev_c)^2
-  const bool roomy = prunable && wave_all(room >= (uint32_t)kEtcA[7]);
+  const bool roomy = prunable && wave_all(skip || room >= (uint32_t)kEtcA[7]);
   const uint32_t dev_max = umax3(dev_rb & 0xffffu, dev_rb >> 16, dev_g);
   ICAMD_ETC1_COUNT(4);
   if (fast) ICAMD_ETC1_COUNT(5);
@@ -290,14 +296,14 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     uint32_t f;
     // (r03) the shortcut costs a dozen instructions per codeword -- less than a pruning test -- so only codewords that
     // would take an exact evaluation are tested
-    if (cw > 0 && fast) fast = wave_all(room >= (uint32_t)kEtcB[cw]);
+    if (cw > 0 && fast) fast = wave_all(skip || room >= (uint32_t)kEtcB[cw]);
     if (fast) {
       // nothing to prune
     } else if (cw > 0 && roomy) {
       const int32_t t = kEtcA[cw] - (int32_t)dev_max;
       // (opaque: left alone the optimiser regroups 24 t^2 into (24 t) * t with a quarter-rate v_mul_lo_u32)
       const int32_t tt = (int32_t)opaque((uint32_t)imad24(t, t, 0));
-      if (wave_all(t > 0 && imad24(tt, 24, 0) > sum_sq - r.score)) { ICAMD_ETC1_COUNT(3); continue; }
+      if (wave_all(skip || (t > 0 && imad24(tt, 24, 0) > sum_sq - r.score))) { ICAMD_ETC1_COUNT(3); continue; }
     } else if (cw > 0 && prunable) {
       const uint32_t a2 = (uint32_t)kEtcA[cw] * 0x00010001u;
       const uint32_t up_rb = pk_subsat_u16(pk_min_u16(a2, room_rb_up), dev_rb);
@@ -305,7 +311,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       const uint32_t ug = umin((uint32_t)kEtcA[cw], room_g_up), dg = umin((uint32_t)kEtcA[cw], room_g_dn);
       const uint32_t up_g = ug - umin(ug, dev_g), dn_g = dg - umin(dg, dev_g);
       const uint32_t lb_up = udot2_u16(up_rb, up_rb, umad24(up_g, up_g, 0u)), lb_dn = udot2_u16(dn_rb, dn_rb, umad24(dn_g, dn_g, 0u));
-      if (wave_all((int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) { ICAMD_ETC1_COUNT(3); continue; }
+      if (wave_all(skip || (int32_t)(8u * umin(lb_up, lb_dn)) > sum_sq - r.score)) { ICAMD_ETC1_COUNT(3); continue; }
     }
     if (fast) {
       ICAMD_ETC1_COUNT(0);
@@ -313,7 +319,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
       f = 0u;  // worked out below if this codeword wins
       fast_mask |= 1u << cw;
     } else {
-      if (TIER && a_fits) a_fits = wave_all(room >= (uint32_t)kEtcA[cw]);
+      if (TIER && a_fits) a_fits = wave_all(skip || room >= (uint32_t)kEtcA[cw]);
       if (TIER && a_fits) {
         ICAMD_ETC1_COUNT(1);
         s = eval_codeword_mixed<FLIP, S>(px, abs2, k0, base, kEtcA[cw], kEtcB[cw], &f);
@@ -336,7 +342,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   // high bit = (s >= 0), low bit = (magnitude a chosen) = (2|s| <= 3 (a + b)).  Both are sign bits of one subtraction,
   // shifted in pixel 7 first; skipped when no lane of the wave was won by a shortcut codeword.
   const bool won_fast = ((fast_mask >> r.cw) & 1u) != 0u;
-  if (!wave_all(!won_fast)) {
+  if (!wave_all(skip || !won_fast)) {
     const uint32_t sh = (r.cw & 3u) * 8u;
     const uint32_t thr = 3u * (bfe(r.cw < 4u ? kEtcModA_lo : kEtcModA_hi, sh, 8) + bfe(r.cw < 4u ? kEtcModB_lo : kEtcModB_hi, sh, 8));
     uint32_t acc = 0;
@@ -383,9 +389,10 @@ struct EtcFlipResult {
 };
 
 // FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
-template <int FLIP, bool TIER = false, bool PRUNE = true>
+template <int FLIP, bool TIER = false, bool PRUNE = true, bool SKIP = false>
 ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
-                                    const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP) {
+                                    const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP,
+                                    bool skip = false) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
   uint32_t q5a[3], q5b[3];
   bool diff_mode = true;
@@ -423,8 +430,8 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
     r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
     r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
   } else {
-    r0 = search_codewords<FLIP, 0, TIER, PRUNE>(px, psum, e0, b0, s0);
-    r1 = search_codewords<FLIP, 1, TIER, PRUNE>(px, psum, e1, b1, s1);
+    r0 = search_codewords<FLIP, 0, TIER, PRUNE, SKIP>(px, psum, e0, b0, s0, skip);
+    r1 = search_codewords<FLIP, 1, TIER, PRUNE, SKIP>(px, psum, e1, b1, s1, skip);
   }
   EtcFlipResult out;
   out.hi = hi | r0.cw << 5 | r1.cw << 2;
@@ -470,7 +477,7 @@ ICAMD_DEV uint32_t assemble_indices(uint32_t f0, uint32_t f1, bool flip) {
 #ifndef ICAMD_ETC1_BUSY_SPREAD
 #define ICAMD_ETC1_BUSY_SPREAD (4u * 141u)
 #endif
-ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
+ICAMD_DEV uint32_t etc1_block_spread(const uint32_t px[16]) {
   uint32_t lo = 0xffffffffu, hi = 0u;
   ICAMD_UNROLL
   for (int p = 0; p < 16; ++p) {
@@ -478,14 +485,74 @@ ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) {
     lo = umin(lo, t);
     hi = umax(hi, t);
   }
-  return wave_count(hi - lo >= ICAMD_ETC1_BUSY_SPREAD) >= 48u;
+  return hi - lo;
+}
+ICAMD_DEV bool etc1_busy_wave(uint32_t spread) { return wave_count(spread >= ICAMD_ETC1_BUSY_SPREAD) >= 48u; }
+ICAMD_DEV bool etc1_busy_wave(const uint32_t px[16]) { return etc1_busy_wave(etc1_block_spread(px)); }
+
+// Per lane: the block is ONE colour (the empty regions of texture atlases, UI, vector art, padding).  Two stages so
+// that other content pays one compare and a vote: the 16 pixels are only compared when the probe's spread is 0 in some
+// lane of the wave.  Byte 3 of a pixel (the ignored alpha of RGBA8 sources) does not count.
+ICAMD_DEV bool etc1_constant_block(const uint32_t px[16], uint32_t spread) {
+  if (wave_all(spread != 0u)) return false;
+  uint32_t diff = 0;
+  ICAMD_UNROLL
+  for (int p = 1; p < 16; ++p) diff |= px[p] ^ px[0];
+  return (diff & 0x00ffffffu) == 0u;
+}
+// etc1_busy_wave among the lanes that take part in the searches (the others are one-colour blocks): three quarters of them
+ICAMD_DEV bool etc1_busy_wave(uint32_t spread, bool skip) {
+  return 4u * wave_count(!skip && spread >= ICAMD_ETC1_BUSY_SPREAD) >= 3u * wave_count(!skip);
+}
+
+// EncodeEtc1Block (etc.cc:545-586) for a block whose 16 pixels are the colour p (R | G << 8 | B << 16), strategies
+// kSplitHorizontally / kSplitVertically / kSmallerError.  Every sub-block of either partition then holds eight copies of
+// p: ComputeAverageColor (etc.cc:299-312) returns p itself, the 5-bit colours of the two halves are equal, so the block
+// is differential with zero differences (etc.cc:486-505), both halves get the same codeword and every pixel the same
+// modifier index -- ONE pixel against the 32 candidates (same keys and tie rules as eval_codeword: first codeword with
+// the strictly smallest error, lowest index inside it) instead of four searches over eight pixels.  The two partitions
+// of kSmallerError tie, which keeps flip = 0 (etc.cc:583).
+ICAMD_DEV Out8 encode_etc1_constant_block(uint32_t p, uint32_t strategy) {
+  const uint32_t pix = p & 0x00ffffffu;
+  uint32_t hi = (strategy == 0u ? 1u : 0u) | 2u;  // kSplitHorizontally is the flip = 1 partition (etc.cc:549-551)
+  uint32_t bch[3];
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    const uint32_t q5 = bfe(pix, 8 * ch, 8) >> 3;   // (8 p) / 8 >> 3
+    hi |= q5 << (27 - 8 * ch);
+    bch[ch] = (q5 << 3) | (q5 >> 2);                // Extend5Bit, color_util.h:200-202
+  }
+  const EtcBase base = { bch[0] << 24 | bch[2] << 8, bch[1] << 8 };
+  int32_t best_e = 0;
+  uint32_t best_cw = 0, best_field = 0;
+  ICAMD_UNROLL
+  for (int cw = 0; cw < 8; ++cw) {
+    uint32_t v[4];
+    int32_t c[4];
+    build_candidates(base, (uint32_t)kEtcA[cw], (uint32_t)kEtcB[cw], v, c);
+    const int32_t k0 = (int32_t)(udot4(pix, v[0], 0u) << 6) + c[0];
+    const int32_t k1 = (int32_t)(udot4(pix, v[1], 0u) << 6) + c[1];
+    const int32_t k2 = (int32_t)(udot4(pix, v[2], 0u) << 6) + c[2];
+    const int32_t k3 = (int32_t)(udot4(pix, v[3], 0u) << 6) + c[3];
+    const int32_t m = imax(imax3(k0, k1, k2), k3);  // 32 E + (3 - k) of the nearest candidate
+    const int32_t e = m >> 5;                        // the sub-block's score is 8 E: comparing E is comparing errors
+    const bool better = cw == 0 || e > best_e;
+    best_e = better ? e : best_e;
+    best_cw = better ? (uint32_t)cw : best_cw;
+    best_field = better ? ((uint32_t)m & 3u) : best_field;
+  }
+  hi |= best_cw << 5 | best_cw << 2;
+  const uint32_t k = 3u - best_field;  // all sixteen pixels take modifier index k: LSB plane in bits 0-15, MSB plane in 16-31
+  const uint32_t lo = ((k & 1u) ? 0x0000ffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u);
+  Out8 o = { perm(0u, hi, 0x00010203u), perm(0u, lo, 0x00010203u) };
+  return o;
 }
 
 // TIER: compile the mixed tier (eval_codeword_mixed) into the codeword searches.  It pays on busy content only and its
 // mere presence costs smooth / flat content 3-5 % (r03 A/B), so the kSmallerError kernels carry both instantiations and
 // pick one per wave (etc1_busy_wave).
-template <bool TIER = false, bool PRUNE = true>
-ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
+template <bool TIER = false, bool PRUNE = true, bool SKIP = false>
+ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy, bool skip = false) {
   // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
   uint32_t qs[4][3];
   ICAMD_UNROLL
@@ -514,10 +581,10 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
   EtcFlipResult res;
   bool flip;
   if (strategy == 0u) {  // kSplitHorizontally: top|bottom only
-    res = encode_flip<1, TIER, PRUNE>(px, psum, top, bottom, false);
+    res = encode_flip<1, TIER, PRUNE, SKIP>(px, psum, top, bottom, false, 1u, skip);
     flip = true;
   } else if (strategy == 1u) {  // kSplitVertically: left|right only
-    res = encode_flip<0, TIER, PRUNE>(px, psum, left, right, false);
+    res = encode_flip<0, TIER, PRUNE, SKIP>(px, psum, left, right, false, 0u, skip);
     flip = false;
   } else if (strategy == 3u) {  // kHeuristic, etc.cc:553-574: one evaluation, partition chosen per lane
     // the reference's fourth quadrant sum uses pixel (2,2) twice and never (3,3) (etc.cc:563-564)
@@ -552,8 +619,8 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy) {
     res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u);
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
-    const EtcFlipResult r0 = encode_flip<0, TIER, PRUNE>(px, psum, left, right, false);
-    const EtcFlipResult r1 = encode_flip<1, TIER, PRUNE>(px, psum, top, bottom, false);
+    const EtcFlipResult r0 = encode_flip<0, TIER, PRUNE, SKIP>(px, psum, left, right, false, 0u, skip);
+    const EtcFlipResult r1 = encode_flip<1, TIER, PRUNE, SKIP>(px, psum, top, bottom, false, 1u, skip);
     // error_lr <= error_tb  <=>  score_lr >= score_tb  (same Sum|p|^2 on both sides)
     flip = !(r0.score >= r1.score);
     res.hi = flip ? r1.hi : r0.hi;

@@ -25,9 +25,27 @@ __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
   uint32_t px[16];
   load_tile_block<COMPS>(P, t, px);
   Out8 c;
-  if (STRATEGY == 3) c = encode_etc1_block<false>(px, 3u);
-  else if (etc1_busy_wave(px)) c = encode_etc1_block<true, false>(px, (uint32_t)STRATEGY);  // busy wave: mixed tier, no pruning
-  else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true>(px, (uint32_t)STRATEGY);            // calm wave: pruning (+ tier?)
+  if (STRATEGY == 3) {
+    c = encode_etc1_block<false>(px, 3u);
+  } else {
+    // One-colour blocks are encoded by a form of their own (one pixel against the 32 candidates).  A wave of nothing else
+    // skips the searches altogether; inside a mixed wave those lanes neither vote in the searches' wave-uniform
+    // decisions nor count for the content probe, and their results are replaced afterwards.
+    const uint32_t spread = etc1_block_spread(px);
+    const bool constant = etc1_constant_block(px, spread);
+    if (wave_all(!constant)) {  // (the common case: exactly the code of a build without the one-colour forms)
+      if (etc1_busy_wave(spread)) c = encode_etc1_block<true, false>(px, (uint32_t)STRATEGY);  // busy wave: mixed tier, no pruning
+      else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true>(px, (uint32_t)STRATEGY);          // calm wave: pruning (+ tier?)
+    } else if (wave_all(constant)) {
+      c = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
+    } else {
+      if (etc1_busy_wave(spread, constant)) c = encode_etc1_block<true, false, true>(px, (uint32_t)STRATEGY, constant);
+      else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true, true>(px, (uint32_t)STRATEGY, constant);
+      const Out8 cc = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
+      c.lo = constant ? cc.lo : c.lo;
+      c.hi = constant ? cc.hi : c.hi;
+    }
+  }
   store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
 }
 

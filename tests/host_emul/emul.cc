@@ -44,7 +44,10 @@ extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_
         const bool tier = (strategy & 0x100) ? true : (strategy & 0x200) ? false : (st != 3u && etc1_busy_wave(px));
         // the instantiations the kernels use: <tier, no pruning> for busy waves, <tier, pruning> for calm ones; bit 10
         // additionally selects the plain <no tier, pruning> form (what the block operations use)
-        Out8 c = (strategy & 0x400) ? encode_etc1_block<false, true>(px, st)
+        // (a "wave" is one block here: the one-colour form is taken for every constant block unless an instantiation is forced)
+        const bool constant = (strategy & 0x700) == 0 && st != 3u && etc1_constant_block(px, etc1_block_spread(px));
+        Out8 c = constant ? encode_etc1_constant_block(px[0], st)
+                 : (strategy & 0x400) ? encode_etc1_block<false, true>(px, st)
                  : tier ? encode_etc1_block<true, false>(px, st) : encode_etc1_block<true, true>(px, st);
         memcpy(o, &c, 8);
       }

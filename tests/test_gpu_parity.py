@@ -181,6 +181,41 @@ def test_large_single_image_16384_dxt1(pkg):
     assert _host(pkg.encode_device(T.ETC1, _dev(img), h, w, 3, etc_strategy=3)) == T.oracle_encode(T.ETC1, img, h, w, 3, 0, 3)
 
 
+def test_etc1_every_colour_as_a_one_colour_block(pkg):
+    """All 2^24 colours as constant 4x4 blocks (the wave-uniform one-colour form of the ETC1 kernels: one pixel against the
+    32 candidates) against the oracle's full search, kSmallerError and kSplitHorizontally; plus images that mix one-colour
+    waves, one-colour blocks inside busy waves and noise, so that all three wave forms run next to each other."""
+    import os
+    import torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+    side = 4096                                   # 4096 x 4096 blocks = every colour once; two halves of 2^23 blocks
+    for half in range(2):
+        idx = torch.arange(half << 23, (half + 1) << 23, dtype=torch.int64, device="cuda").reshape(side // 2, side)
+        rgb = torch.stack([idx & 255, (idx >> 8) & 255, idx >> 16], dim=2).to(torch.uint8)   # (2048, 4096, 3) block colours
+        src = rgb.repeat_interleave(4, dim=0).repeat_interleave(4, dim=1).contiguous()        # 8192 x 16384 px
+        del idx, rgb
+        h, w = src.shape[0], src.shape[1]
+        host = src.cpu().numpy()
+        for strategy in (2, 0):
+            got = _host(pkg.encode_device(T.ETC1, src, h, w, 3, etc_strategy=strategy))
+            want = T.oracle_encode(T.ETC1, host, h, w, 3, 0, strategy, threads=cores)
+            assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), (half, strategy)
+        del src, host
+    g = np.random.Generator(np.random.PCG64(31))
+    h = w = 1024
+    img = g.integers(0, 256, size=(h // 16, w // 16, 1, 1, 3), dtype=np.uint8)               # 16 x 16 px tiles of one colour
+    img = np.broadcast_to(img, (h // 16, w // 16, 16, 16, 3)).transpose(0, 2, 1, 3, 4).reshape(h, w, 3).copy()
+    noisy = g.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    tile_is_noise = np.repeat(np.repeat(g.random((h // 16, w // 16)) < 0.2, 16, axis=0), 16, axis=1)
+    img[tile_is_noise] = noisy[tile_is_noise]
+    img[512:, :512] = noisy[512:, :512]
+    for comps in (3, 4):
+        im = img if comps == 3 else np.concatenate([img, noisy[..., :1]], axis=2)
+        for strategy in (0, 1, 2):
+            assert _host(pkg.encode_device(T.ETC1, _dev(im), h, w, comps, etc_strategy=strategy)) == \
+                T.oracle_encode(T.ETC1, im, h, w, comps, 0, strategy, threads=8), (comps, strategy)
+
+
 def test_etc1_batch_1024(pkg):
     import torch
     # config 4 shape (1024x1024 textures, batch sharded over GPUs): a per-GPU sub-batch here, oracle on 2 of them

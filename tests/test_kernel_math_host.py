@@ -324,6 +324,43 @@ def test_pvrtc_decode_properties():
     assert 10 * np.log10(255 * 255 / mse) > 30.0
 
 
+def constant_block_strip(colours, comps, alpha=None):
+    """One 4x4 block per colour, every pixel of a block that colour (alpha, if any, varies inside the block: ignored)."""
+    n = len(colours)
+    px = np.repeat(np.asarray(colours, np.uint8).reshape(n, 1, 3), 16, axis=1)
+    if comps == 4:
+        a = np.arange(n * 16, dtype=np.uint32).reshape(n, 16, 1) * 37 if alpha is None else alpha
+        px = np.concatenate([px, (a & 255).astype(np.uint8)], axis=2)
+    return np.ascontiguousarray(px.reshape(n, 4, 4, comps).transpose(1, 0, 2, 3).reshape(4, 4 * n, comps))
+
+
+def test_etc1_one_colour_blocks(emul):
+    """The one-colour form of the ETC1 encoder (encode_etc1_constant_block: one pixel against the 32 candidates instead
+    of four searches) against the oracle's full search (etc.cc:545-586): every grey level, every value of one channel
+    against dark / bright others, the colours next to every 5-bit step, and 2^19 random colours; all three searching
+    strategies, RGB and RGBA (alpha ignored) sources.  The GPU tier sweeps all 2^24 colours."""
+    g = np.random.Generator(np.random.PCG64(2024))
+    cols = [(v, v, v) for v in range(256)]
+    for ch in range(3):
+        for other in (0, 7, 8, 128, 247, 248, 255):
+            for v in range(256):
+                c = [other] * 3
+                c[ch] = v
+                cols.append(tuple(c))
+    cols += [tuple(int(x) for x in r) for r in g.integers(0, 256, size=(1 << 19, 3))]
+    cols = np.array(cols, np.uint8)
+    n = len(cols)
+    for comps, strategy in ((3, 2), (3, 0), (3, 1), (4, 2)):
+        strip = constant_block_strip(cols, comps)
+        want = T.oracle_encode(T.ETC1, strip, 4, 4 * n, comps, 0, strategy)
+        got = emul_encode(emul, T.ETC1, strip, 4, 4 * n, comps, 0, strategy)
+        if got != want:
+            bad = [i for i in range(n) if got[i * 8:(i + 1) * 8] != want[i * 8:(i + 1) * 8]]
+            raise AssertionError((comps, strategy, len(bad), [tuple(cols[i]) for i in bad[:5]]))
+        # ... and the general forms agree on the same blocks (the kernel takes them when a wave is not all one-colour)
+        assert emul_encode(emul, T.ETC1, strip[:, :4 * 4096], 4, 4 * 4096, comps, 0, strategy | 0x200) == want[:8 * 4096]
+
+
 def etc_shortcut_blocks(g, n, comps):
     """n 4x4 blocks (4 x 4n strip) aimed at the unclamped shortcut of etc1_block.h: mid-tone base colours (so that the
     shortcut applies up to some codeword) with per-pixel deviations drawn around the decision points 2|s| = 3 (a + b)
