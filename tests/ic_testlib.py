@@ -378,7 +378,7 @@ SOAK_FORMATS = [(DXT1, 3, 0, 2), (DXT1, 3, 1, 2), (DXT1, 4, 0, 2), (DXT1, 4, 1, 
 
 
 def soak_image(rng, h, w, comps):
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     if kind == 0:    # full-range noise
         img = rng.integers(0, 256, (h, w, comps), dtype=np.uint8)
     elif kind == 1:  # mid-tones only: every ETC1 codeword up to b = 80 stays unclamped (wave-uniform shortcut fires)
@@ -389,6 +389,11 @@ def soak_image(rng, h, w, comps):
     elif kind == 3:  # few distinct colours (constant-colour blocks, ties)
         pal = rng.integers(0, 256, (3, comps), dtype=np.uint8)
         img = pal[rng.integers(0, 3, (h // 4 + 1, w // 4 + 1))].repeat(4, axis=0).repeat(4, axis=1)[:h, :w]
+    elif kind == 5:  # 16 x 16 tiles of one colour, a quarter of them noise: one-colour blocks next to busy ones in a wave
+        th, tw = h // 16 + 1, w // 16 + 1
+        img = rng.integers(0, 256, (th, tw, comps), dtype=np.uint8).repeat(16, axis=0).repeat(16, axis=1)[:h, :w].copy()
+        noisy = (rng.random((th, tw)) < 0.25).repeat(16, axis=0).repeat(16, axis=1)[:h, :w]
+        img[noisy] = rng.integers(0, 256, (int(noisy.sum()), comps), dtype=np.uint8)
     else:            # gradients plus a little noise
         y, x = np.mgrid[0:h, 0:w]
         base = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(h - 1, 1)), ((x + y) * 255 // max(h + w - 2, 1)),
