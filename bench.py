@@ -427,7 +427,44 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     per = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     med = _median(per)
     algo = size * size * bytes_per_px
+    # The same calls captured once into a HIP graph (one call per distinct texture) and replayed: what a caller with many
+    # single textures gets when the host's per-call launch cost is taken out (PVRTC needs its scratch
+    # memory handed over for the capture, icamd_pvrtc2_set_workspace).
+    graph = None
+    try:
+        gs = torch.cuda.Stream(device=src.device)
+        ws = torch.empty(max(1, pkg.pvrtc_workspace_size(size, 1)), dtype=torch.uint8, device=src.device) if codec == 3 else None
+        with torch.cuda.stream(gs):
+            if ws is not None:
+                pkg.pvrtc_set_workspace(ws)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=gs):
+                    for k in range(batch):
+                        pkg.encode_device(codec, src[k], size, size, comps, etc_strategy=strategy, n_images=1,
+                                          out=out[k:k + 1], stream=gs)
+            finally:
+                if ws is not None:
+                    pkg.pvrtc_set_workspace(None)
+            for _ in range(3):
+                g.replay()
+            gs.synchronize()
+            reps = max(8, min(200, calls // batch))
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            for i in range(reps):
+                marks[i].record(gs)
+                g.replay()
+            marks[reps].record(gs)
+            gs.synchronize()
+        gper = _median([marks[i].elapsed_time(marks[i + 1]) for i in range(reps)]) / batch
+        graph = {"calls_per_graph": batch, "replays": reps, "median_ms_per_call": round(gper, 5),
+                 "value": round(size * size / (gper * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                 "frac": round(algo / (gper * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        del g
+    except Exception as e:  # a diagnostic leg: never fatal
+        graph = "unavailable: %s" % e
     return {
+        "graph_replay": graph,
         "texture": [size, size], "distinct_textures_rotated": batch, "distinct_source_MiB": distinct_bytes >> 20,
         "calls": calls, "median_ms_per_call": round(med, 5), "min_ms": round(min(per), 5), "max_ms": round(max(per), 5),
         "back_to_back_ms_per_call_wall": round(wall / calls * 1e3, 5),
