@@ -955,36 +955,85 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
         (void)hipGetLastError();
       }
       std::unique_ptr<Staging> st = pool_take(dev);
-      // images without an output buffer of their own (gather only) are encoded into one of two scratch buffers, so
-      // that the peer copy of image j overlaps the encode of image j + 1 (two streams, alternating)
-      bool need_scratch = false;
-      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices)
-        if (gather && (!d_dsts || !d_dsts[i]) && dev != gather_device) need_scratch = true;
-      if (st->ensure(need_scratch ? out_size : 1, need_scratch ? out_size : 1) != ICAMD_OK) {
+      // this worker's images, in order
+      std::vector<uint32_t> mine;
+      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) mine.push_back(i);
+      auto slot_of = [&](uint32_t i) { return static_cast<uint8_t *>(d_gathered) + (size_t)i * gathered_image_stride_bytes; };
+      // where image i is encoded to: its own buffer, its gather slot (images of the gather device), or scratch (nullptr here)
+      auto target_of = [&](uint32_t i) -> uint8_t * {
+        if (d_dsts && d_dsts[i]) return static_cast<uint8_t *>(d_dsts[i]);
+        return (gather && dev == gather_device) ? slot_of(i) : nullptr;
+      };
+      // Consecutive images of a worker whose sources AND targets are evenly spaced (a batch laid out as one array, the
+      // usual case) go out as ONE launch of up to kRun images: a 1024^2 texture alone fills a quarter of the chip's wave
+      // slots, so one launch per texture leaves an MI355X mostly idle (bench.py single_image: 97 vs 252 Gpix/s for ETC1).
+      const size_t kRun = 64;
+      auto run_length = [&](size_t j, size_t *src_stride, size_t *dst_stride) -> size_t {
+        const uint32_t i0 = mine[j];
+        if (!d_srcs[i0] || j + 1 >= mine.size() || !d_srcs[mine[j + 1]]) return 1;
+        const uint8_t *s0 = static_cast<const uint8_t *>(d_srcs[i0]), *s1 = static_cast<const uint8_t *>(d_srcs[mine[j + 1]]);
+        uint8_t *t0 = target_of(i0), *t1 = target_of(mine[j + 1]);
+        if (s1 <= s0 || (t0 == nullptr) != (t1 == nullptr) || (t0 && t1 <= t0)) return 1;
+        const size_t ss = (size_t)(s1 - s0), ds = t0 ? (size_t)(t1 - t0) : out_size;
+        if (ds < out_size || ss % 16u || ds % 16u) return 1;  // (PVRTC wants 16-byte strides; harmless for the others)
+        size_t len = 2;
+        while (len < kRun && j + len < mine.size()) {
+          const uint32_t in = mine[j + len];
+          const uint8_t *sn = static_cast<const uint8_t *>(d_srcs[in]);
+          uint8_t *tn = target_of(in);
+          if (!sn || sn != s0 + len * ss || (tn == nullptr) != (t0 == nullptr) || (t0 && tn != t0 + len * ds)) break;
+          ++len;
+        }
+        *src_stride = ss;
+        *dst_stride = ds;
+        return len;
+      };
+      // scratch for the images that have no buffer on this device (gather only): two halves, so that the peer copies of
+      // one run overlap the encode of the next (two streams, alternating)
+      size_t scratch_images = 0;
+      for (size_t j = 0; j < mine.size(); ++j)
+        if (gather && target_of(mine[j]) == nullptr) scratch_images = std::min(kRun, std::max<size_t>(scratch_images + 1, 1));
+      const size_t scratch_bytes = scratch_images ? scratch_images * out_size : 1;
+      if (st->ensure(scratch_bytes, scratch_bytes) != ICAMD_OK) {
         pool_give(std::move(st));
         return fail_all(ICAMD_ERR_ALLOC, "staging allocation failed");
       }
-      uint32_t j = 0;
-      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices, ++j) {
-        hipStream_t s = (j & 1u) ? st->stream2 : st->stream;
-        uint8_t *slot = gather ? static_cast<uint8_t *>(d_gathered) + (size_t)i * gathered_image_stride_bytes : nullptr;
-        void *own = d_dsts ? d_dsts[i] : nullptr;
-        void *target = own ? own : (dev == gather_device ? static_cast<void *>(slot) : ((j & 1u) ? st->d_in : st->d_out));
-        if (!d_srcs[i]) { local[i] = ICAMD_FALSE; continue; }
+      size_t run_no = 0;
+      for (size_t j = 0; j < mine.size(); ++run_no) {
+        size_t src_stride = 0, dst_stride = 0;
+        size_t len = run_length(j, &src_stride, &dst_stride);
+        const uint32_t i0 = mine[j];
+        hipStream_t s = (run_no & 1u) ? st->stream2 : st->stream;
+        uint8_t *scratch = static_cast<uint8_t *>((run_no & 1u) ? st->d_in : st->d_out);
+        uint8_t *own = target_of(i0);
+        if (!own && gather) len = std::min(len, scratch_images);
+        auto set_all = [&](int code) { for (size_t k = 0; k < len; ++k) local[mine[j + k]] = code; };
+        if (!d_srcs[i0]) { local[i0] = ICAMD_FALSE; j += 1; continue; }
         if (!own && !gather) {  // nowhere to put this image's blocks
-          local[i] = ICAMD_ERR_ARG;
+          local[i0] = ICAMD_ERR_ARG;
           if (errors[(size_t)d].empty()) errors[(size_t)d] = "icamd_encode_batch_sharded_device: image without an output buffer";
+          j += 1;
           continue;
         }
-        local[i] = icamd_encode_device(codec, etc_strategy, src_components, swap_rb, height, width, height, width,
-                                       row_stride_bytes, 1, 0, 0, d_srcs[i], target, s);
-        if (local[i] == ICAMD_OK && gather && target != slot) {
-          // the encoded image travels device -> device (xGMI between GPUs); no host staging
-          const hipError_t e = dev == gather_device ? hipMemcpyAsync(slot, target, out_size, hipMemcpyDeviceToDevice, s)
-                                                    : hipMemcpyPeerAsync(slot, gather_device, target, dev, out_size, s);
-          if (e != hipSuccess) local[i] = fail(ICAMD_ERR_HIP, "gather copy", e);
+        uint8_t *target = own ? own : scratch;
+        const int rc_run = icamd_encode_device(codec, etc_strategy, src_components, swap_rb, height, width, height, width,
+                                               row_stride_bytes, (uint32_t)len, len > 1 ? src_stride : 0,
+                                               len > 1 ? (own ? dst_stride : out_size) : 0, d_srcs[i0], target, s);
+        set_all(rc_run);
+        if (rc_run == ICAMD_OK && gather) {
+          for (size_t k = 0; k < len; ++k) {
+            const uint32_t i = mine[j + k];
+            uint8_t *from = own ? own + k * dst_stride : scratch + k * out_size;
+            if (from == slot_of(i)) continue;  // encoded straight into its slot
+            // the encoded image travels device -> device (xGMI between GPUs); no host staging
+            const hipError_t e = dev == gather_device ? hipMemcpyAsync(slot_of(i), from, out_size, hipMemcpyDeviceToDevice, s)
+                                                      : hipMemcpyPeerAsync(slot_of(i), gather_device, from, dev, out_size, s);
+            if (e != hipSuccess) local[i] = fail(ICAMD_ERR_HIP, "gather copy", e);
+          }
         }
-        if (local[i] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
+        for (size_t k = 0; k < len; ++k)
+          if (local[mine[j + k]] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
+        j += len;
       }
       const hipError_t e1 = hipStreamSynchronize(st->stream), e2 = hipStreamSynchronize(st->stream2);
       if (e1 != hipSuccess || e2 != hipSuccess) fail_all(ICAMD_ERR_HIP, "stream synchronize failed");

@@ -925,6 +925,38 @@ def test_sharded_device_batch_one_gpu_listed_several_times(pkg):
         pkg.encode_batch_sharded_device(pkg.DXT1, [src, src], 64, 64, 4, [0], outs=[good, None])
 
 
+def test_sharded_device_batch_of_evenly_spaced_images(pkg):
+    """Images laid out as one array (sources and outputs evenly spaced) go out as batched launches, up to 64 per launch;
+    an image that breaks the spacing splits the runs.  Same bytes as one call per image."""
+    import torch
+    for codec, comps, size, n in ((pkg.DXT1, 4, 128, 23), (pkg.ETC1, 3, 64, 200), (pkg.PVRTC2, 4, 64, 23), (pkg.DXT5, 4, 64, 9)):
+        imgs = np.stack([T.s_mixed(size, size, comps, index=900 + i) for i in range(n)])
+        want = [T.oracle_encode(codec, imgs[i], size, size, comps, 0, 2) for i in range(n)]
+        per = pkg.encoded_size(codec, size, size)
+        src = torch.from_numpy(imgs).cuda()
+        for devices in ([0], [0, 0, 0]):
+            srcs = [src[i] for i in range(n)]
+            out = torch.zeros((n, per), dtype=torch.uint8, device="cuda")
+            st, _, _ = pkg.encode_batch_sharded_device(codec, srcs, size, size, comps, devices, outs=[out[i] for i in range(n)])
+            assert st == [0] * n
+            o = out.cpu().numpy()
+            assert all(o[i].tobytes() == want[i] for i in range(n)), (codec, devices, "outs")
+            # gather only, padded slots (slot spacing = len(devices) x the gather stride within a worker)
+            gathered = torch.zeros((n, per + 32), dtype=torch.uint8, device="cuda")
+            st, _, gathered = pkg.encode_batch_sharded_device(codec, srcs, size, size, comps, devices, gather_device=0,
+                                                              gathered=gathered)
+            g = gathered.cpu().numpy()
+            assert st == [0] * n and all(g[i, :per].tobytes() == want[i] and not g[i, per:].any() for i in range(n))
+            # an image elsewhere in memory in the middle of the array, and one missing source
+            lone = src[n // 2].clone()
+            srcs2 = list(srcs)
+            srcs2[n // 2] = lone
+            out.zero_()
+            st, _, _ = pkg.encode_batch_sharded_device(codec, srcs2, size, size, comps, devices, outs=[out[i] for i in range(n)])
+            o = out.cpu().numpy()
+            assert st == [0] * n and all(o[i].tobytes() == want[i] for i in range(n)), (codec, devices, "split runs")
+
+
 def test_sharded_device_batch_on_distinct_gpus(pkg):
     import torch
     if torch.cuda.device_count() < 2:
