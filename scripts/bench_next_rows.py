@@ -59,3 +59,17 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         print("transcode dxt1->etc1 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms)" % (px / t / 1e6, 2 * work.numel() / t / 1e9, t * 1e3))
     del out, dn, blocks
     torch.cuda.empty_cache()
+
+# PVRTC 2 bpp decoder (extension: the reference has none, pvrtc_compressor.cc:669-672)
+src = torch.randint(0, 256, (batch, n, n, 4), dtype=torch.uint8, device=dev, generator=g)
+blocks = pkg.encode_device(3, src, n, n, 4, n_images=batch)
+torch.cuda.synchronize()
+del src
+out = torch.empty((batch, n * n * 4), dtype=torch.uint8, device=dev)
+def dec_pvrtc():
+    rc = L.icamd_decode_device(3, 0, n, n, 0, batch, blocks.shape[1], out.shape[1], ctypes.c_void_p(blocks.data_ptr()),
+                               ctypes.c_void_p(out.data_ptr()), sh)
+    assert rc == 0
+t = timeit(dec_pvrtc)
+print("decode pvrtc %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)" % (
+    batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n))
