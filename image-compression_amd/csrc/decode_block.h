@@ -152,48 +152,123 @@ ICAMD_DEV uint32_t pvrtc_stored_weight(uint32_t data, bool two_bpp, uint32_t x, 
   return (0x08050300u >> (8u * s)) & 0xffu;
 }
 
-// One 8x4 block.  words[d] = {modulation word, colour word} of the blocks at (dx, dy) = nb index 3*(dy+1)+(dx+1),
+// One 8x4 block.  mod[d] / col[d] = modulation word / colour word of the blocks at (dx, dy) = index 3*(dy+1)+(dx+1),
 // toroidal wrap applied by the caller.  px[8*y + x] = decoded R,G,B,A dword.
-ICAMD_DEV void decode_pvrtc2_block(const uint32_t mod[9], const uint32_t col[9], uint32_t px[32]) {
-  PvrtcAB nb[3][3];
-  ICAMD_UNROLL
-  for (int i = 0; i < 9; ++i) {
-    uint32_t a, b;
-    pvrtc_unpack_colors(col[i], a, b);
-    PvrtcAB e = { pair_rb(a), pair_ga(a), pair_rb(b), pair_ga(b) };
-    nb[i / 3][i % 3] = e;
-  }
+//
+// Weights (of colour B, in eighths) are handled as BYTES, four pixels per dword (r03):
+//   * the block's own stored weights of a pixel row are expanded from the row's 8 modulation bits by shifts and masks
+//     (1BPP: bit -> 0 / 8; 2BPP: the four 2-bit samples s -> 3 s - (s >> 1) = {0, 3, 5, 8}, placed at the even-parity
+//     pixels; the two samples whose low bit is a sub-mode flag -- bit positions 0 and 20, pvrtc.cc:474-487 -- keep only
+//     their high bit);
+//   * the weights a 2BPP block does NOT store (odd checkerboard parity) are the mode's average of the orthogonal
+//     neighbours' stored weights, computed on the packed bytes: (l + r + u + d + 2) >> 2 needs no carries between bytes
+//     (4 * 8 + 2 < 256); only the 12 border weights come from the neighbour blocks' words, one by one.
+// Colours follow the encoder's separable walk (pvrtc_row_mods_v): the three block columns are blended vertically once
+// per pixel row, then P(xw + 1) = P(xw) + (VR - VL) steps through each half row with P = 256 * colour on 16-bit lanes,
+// whose high bytes are the reference's truncated 8-bit channels (pvrtc.cc:228-236); the final blend
+// ((8 - w) A + w B) >> 3 (ApplyModulation, pvrtc.cc:120-144) is three packed 16-bit instructions per channel pair.
+// A block's two colours as the four channel pairs the interpolation works on: a_rb, a_ga, b_rb, b_ga.
+ICAMD_DEV void pvrtc_expand_colors(uint32_t colour_word, uint32_t out[4]) {
+  uint32_t a, b;
+  pvrtc_unpack_colors(colour_word, a, b);
+  out[0] = pair_rb(a); out[1] = pair_ga(a); out[2] = pair_rb(b); out[3] = pair_ga(b);
+}
+
+// C[r][c][v]: expanded colours of the 3 x 3 block neighbourhood.  mod / col are indexed like the neighbourhood
+// (3 * (dy + 1) + dx + 1) but only the block's own words (4) and its four orthogonal neighbours' (1, 3, 5, 7) are read.
+ICAMD_DEV void decode_pvrtc2_block_expanded(const uint32_t C[3][3][4], const uint32_t mod[9], const uint32_t col[9],
+                                            uint32_t px[32]) {
   const uint32_t data = mod[4];
   const bool two = (col[4] & 1u) != 0u;
+
+  // ---- stored weights of the block's own pixels: W[y][h], byte x & 3 of W[y][x >> 2] (0 where nothing is stored)
+  uint32_t W[4][2];
   ICAMD_UNROLL
   for (int y = 0; y < 4; ++y) {
+    const uint32_t bits = (data >> (8 * y)) & 0xffu;
+    // 1BPP: bit x of the row -> 8 * bit in byte x
+    const uint32_t lo = bits & 0xfu, hi = bits >> 4;
+    const uint32_t one0 = ((lo | lo << 7 | lo << 14 | lo << 21) & 0x01010101u) << 3;
+    const uint32_t one1 = ((hi | hi << 7 | hi << 14 | hi << 21) & 0x01010101u) << 3;
+    // 2BPP: sample j (2 bits) of the row belongs to pixel x = 2 j + (y & 1)
+    const uint32_t S = (bits | bits << 6 | bits << 12 | bits << 18) & 0x03030303u;  // byte j = s_j
+    uint32_t w4 = 3u * S - ((S >> 1) & 0x01010101u);                                  // byte j = {0, 3, 5, 8}[s_j]
+    if (y == 0) w4 = (w4 & 0xffffff00u) | ((S & 0x00000002u) << 2);                   // bit position 0: (s >> 1) * 8
+    if (y == 2) w4 = (w4 & 0xff00ffffu) | ((S & 0x00020000u) << 2);                   // bit position 20
+    const uint32_t two0 = perm(0u, w4, (y & 1) ? 0x010c000cu : 0x0c010c00u);
+    const uint32_t two1 = perm(0u, w4, (y & 1) ? 0x030c020cu : 0x0c030c02u);
+    W[y][0] = two ? two0 : one0;
+    W[y][1] = two ? two1 : one1;
+  }
+  // ---- the 12 weights of neighbouring blocks that the block's unstored pixels look at (all of even parity there)
+  const uint32_t l1 = pvrtc_stored_weight(mod[3], (col[3] & 1u) != 0u, 7u, 1u), l3 = pvrtc_stored_weight(mod[3], (col[3] & 1u) != 0u, 7u, 3u);
+  const uint32_t r0 = pvrtc_stored_weight(mod[5], (col[5] & 1u) != 0u, 0u, 0u), r2 = pvrtc_stored_weight(mod[5], (col[5] & 1u) != 0u, 0u, 2u);
+  uint32_t up[2] = { 0u, 0u }, dn[2] = { 0u, 0u };
+  ICAMD_UNROLL
+  for (int x = 0; x < 8; ++x) {
+    if (x & 1) up[x >> 2] |= pvrtc_stored_weight(mod[1], (col[1] & 1u) != 0u, (uint32_t)x, 3u) << (8 * (x & 3));
+    else dn[x >> 2] |= pvrtc_stored_weight(mod[7], (col[7] & 1u) != 0u, (uint32_t)x, 0u) << (8 * (x & 3));
+  }
+  // ---- weights of all 32 pixels
+  const bool avg4 = (data & 1u) == 0u, vertical = (data & (1u << 20)) != 0u;
+  uint32_t Wf[4][2];
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const uint32_t lcol = y == 1 ? l1 : y == 3 ? l3 : 0u;            // left of pixel 0 (only odd rows look there)
+    const uint32_t rcol = y == 0 ? r0 : y == 2 ? r2 : 0u;            // right of pixel 7 (only even rows)
+    const uint32_t left[2] = { W[y][0] << 8 | lcol, alignbit(W[y][1], W[y][0], 24) };
+    const uint32_t right[2] = { alignbit(W[y][1], W[y][0], 8), W[y][1] >> 8 | rcol << 24 };
     ICAMD_UNROLL
-    for (int x = 0; x < 8; ++x) {
-      uint32_t w;
-      if (!two || ((x ^ y) & 1) == 0) {
-        w = pvrtc_stored_weight(data, two, (uint32_t)x, (uint32_t)y);
-      } else {
-        // the four orthogonal neighbours all store a weight (even checkerboard parity, or a 1BPP block)
-        const int lb = x == 0 ? 3 : 4, rb = x == 7 ? 5 : 4, ub = y == 0 ? 1 : 4, db = y == 3 ? 7 : 4;
-        const uint32_t l = pvrtc_stored_weight(mod[lb], (col[lb] & 1u) != 0u, (uint32_t)((x + 7) & 7), (uint32_t)y);
-        const uint32_t r = pvrtc_stored_weight(mod[rb], (col[rb] & 1u) != 0u, (uint32_t)((x + 1) & 7), (uint32_t)y);
-        const uint32_t u = pvrtc_stored_weight(mod[ub], (col[ub] & 1u) != 0u, (uint32_t)x, (uint32_t)((y + 3) & 3));
-        const uint32_t d = pvrtc_stored_weight(mod[db], (col[db] & 1u) != 0u, (uint32_t)x, (uint32_t)((y + 1) & 3));
-        w = !(data & 1u) ? (l + r + u + d + 2u) >> 2 : (data & (1u << 20)) ? (u + d + 1u) >> 1 : (l + r + 1u) >> 1;
-      }
-      // GetInterpolatedColor2BPP (pvrtc.cc:208-237): 2x2 sources and weights of pixel (x, y)
-      const int x0 = x < 4 ? 0 : 1, y0 = y < 2 ? 0 : 1;
-      const uint32_t xw = (uint32_t)((x + 4) & 7), yw = (uint32_t)((y + 2) & 3);
-      const PvrtcAB &c00 = nb[y0][x0], &c01 = nb[y0][x0 + 1], &c10 = nb[y0 + 1][x0], &c11 = nb[y0 + 1][x0 + 1];
-      const uint32_t a_rb = bilerp_pair(c00.a_rb, c01.a_rb, c10.a_rb, c11.a_rb, xw, yw);
-      const uint32_t a_ga = bilerp_pair(c00.a_ga, c01.a_ga, c10.a_ga, c11.a_ga, xw, yw);
-      const uint32_t b_rb = bilerp_pair(c00.b_rb, c01.b_rb, c10.b_rb, c11.b_rb, xw, yw);
-      const uint32_t b_ga = bilerp_pair(c00.b_ga, c01.b_ga, c10.b_ga, c11.b_ga, xw, yw);
-      const uint32_t rbv = (((8u - w) * a_rb + w * b_rb) >> 3) & 0x00ff00ffu;
-      const uint32_t gav = (((8u - w) * a_ga + w * b_ga) >> 3) & 0x00ff00ffu;
-      px[8 * y + x] = unpair(rbv, gav);
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t u = y > 0 ? W[y - 1][h] : up[h], d = y < 3 ? W[y + 1][h] : dn[h];
+      const uint32_t a4 = ((left[h] + right[h] + u + d + 0x02020202u) >> 2) & 0x0f0f0f0fu;
+      const uint32_t av = ((u + d + 0x01010101u) >> 1) & 0x0f0f0f0fu;
+      const uint32_t ah = ((left[h] + right[h] + 0x01010101u) >> 1) & 0x0f0f0f0fu;
+      const uint32_t interp = avg4 ? a4 : vertical ? av : ah;
+      const uint32_t stored_at = (y & 1) ? 0xff00ff00u : 0x00ff00ffu;  // even checkerboard parity
+      Wf[y][h] = two ? ((W[y][h] & stored_at) | (interp & ~stored_at)) : W[y][h];
     }
   }
+  // ---- colours
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const int r0b = y < 2 ? 0 : 1;                     // block rows (r0b, r0b + 1) bracket this pixel row
+    const uint32_t yw = (uint32_t)((y + 2) & 3);
+    uint32_t V[3][4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] = vblend_pair(yw, C[r0b][c][v], C[r0b + 1][c][v]);
+    ICAMD_UNROLL
+    for (int h = 0; h < 2; ++h) {
+      uint32_t P[4], D[4];
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t vl = V[h][v], vr = V[h + 1][v];
+        D[v] = vr - vl;
+        P[v] = h == 0 ? (vl + vr) << 2 : vl << 3;     // xw = 4 / xw = 0
+      }
+      ICAMD_UNROLL
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w2 = perm(0u, Wf[y][h], 0x0c000c00u + (uint32_t)j * 0x00010001u);  // {w, 0, w, 0} of byte j
+        const uint32_t iw2 = 0x00080008u - w2;
+        const uint32_t rb = pk_lshr16(pk_mad_u16(pk_lshr16(P[2], 8), w2, pk_mad_u16(pk_lshr16(P[0], 8), iw2, 0u)), 3);
+        const uint32_t ga = pk_lshr16(pk_mad_u16(pk_lshr16(P[3], 8), w2, pk_mad_u16(pk_lshr16(P[1], 8), iw2, 0u)), 3);
+        px[8 * y + 4 * h + j] = unpair(rb, ga);
+        if (j < 3) {
+          ICAMD_UNROLL
+          for (int v = 0; v < 4; ++v) P[v] += D[v];
+        }
+      }
+    }
+  }
+}
+
+ICAMD_DEV void decode_pvrtc2_block(const uint32_t mod[9], const uint32_t col[9], uint32_t px[32]) {
+  uint32_t C[3][3][4];  // [block row][block column][a_rb, a_ga, b_rb, b_ga]
+  ICAMD_UNROLL
+  for (int i = 0; i < 9; ++i) pvrtc_expand_colors(col[i], C[i / 3][i % 3]);
+  decode_pvrtc2_block_expanded(C, mod, col, px);
 }
 
 }  // namespace icamd

@@ -90,11 +90,73 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_kern
   decode_pvrtc2_block(mod, col, px);
   uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * P.row_stride + (size_t)bx * 32u;
 #pragma unroll
+  for (int y = 0; y < 4; ++y) {  // (one 64-bit product above; the rows advance by additions)
+    U4 v0 = { px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3] };
+    U4 v1 = { px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7] };
+    *reinterpret_cast<U4 *>(dst) = v0;
+    *reinterpret_cast<U4 *>(dst + 16) = v1;
+    dst += P.row_stride;
+  }
+}
+// The same for textures of 256^2 and more (block grids at least 32 x 64): one workgroup per TILE of 32 x 8 blocks.  Every
+// lane expands its own block's colour word once (the packed-field -> channel-pair expansion is a quarter of the per-block
+// work when each lane does it for all nine neighbours), the 84 blocks of the one-block ring around the tile are expanded
+// by the first 84 lanes, the pairs (16 B per block) meet in LDS, one barrier.  The modulation / mode words of the four
+// orthogonal neighbours still come from memory (L1 hits).
+constexpr uint32_t kPvrtcTileW = 32, kPvrtcTileH = 8;
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile_kernel(DecodeParams P) {
+  __shared__ U4 pairs[(kPvrtcTileH + 2) * (kPvrtcTileW + 2)];
+  const uint32_t log2_cols = 31u - (uint32_t)__builtin_clz(P.block_cols), log2_rows = 31u - (uint32_t)__builtin_clz(P.block_rows);
+  const uint32_t tiles_x = P.block_cols >> 5, log2_tx = log2_cols - 5u, log2_tiles = log2_tx + log2_rows - 3u;
+  const uint32_t img = blockIdx.x >> log2_tiles, tile = blockIdx.x & ((1u << log2_tiles) - 1u);
+  const uint32_t bx0 = (tile & (tiles_x - 1u)) << 5, by0 = (tile >> log2_tx) << 3;
+  const uint32_t cmask = P.block_cols - 1u, rmask = P.block_rows - 1u;
+  const U2 *blocks = reinterpret_cast<const U2 *>(P.blocks + (size_t)img * P.src_image_stride);
+  const uint32_t lx = threadIdx.x & 31u, ly = threadIdx.x >> 5;
+  const uint32_t bx = bx0 + lx, by = by0 + ly;
+  auto word_at = [&](uint32_t x, uint32_t y) { return blocks[spread_bits16(x & cmask) << 1 | spread_bits16(y & rmask)]; };
+  auto publish = [&](uint32_t cell, uint32_t colour_word) {
+    uint32_t e[4];
+    pvrtc_expand_colors(colour_word, e);
+    const U4 v = { e[0], e[1], e[2], e[3] };
+    pairs[cell] = v;
+  };
+  const U2 own = word_at(bx, by);
+  publish((ly + 1u) * (kPvrtcTileW + 2u) + lx + 1u, own.y);
+  if (threadIdx.x < 2u * (kPvrtcTileW + 2u) + 2u * kPvrtcTileH) {  // the ring: top row, bottom row, left column, right column
+    const uint32_t t = threadIdx.x;
+    uint32_t cx, cy;  // cell coordinates in the (W + 2) x (H + 2) array
+    if (t < kPvrtcTileW + 2u) { cx = t; cy = 0u; }
+    else if (t < 2u * (kPvrtcTileW + 2u)) { cx = t - (kPvrtcTileW + 2u); cy = kPvrtcTileH + 1u; }
+    else if (t < 2u * (kPvrtcTileW + 2u) + kPvrtcTileH) { cx = 0u; cy = t - 2u * (kPvrtcTileW + 2u) + 1u; }
+    else { cx = kPvrtcTileW + 1u; cy = t - 2u * (kPvrtcTileW + 2u) - kPvrtcTileH + 1u; }
+    publish(cy * (kPvrtcTileW + 2u) + cx, word_at(bx0 + cx - 1u, by0 + cy - 1u).y);
+  }
+  uint32_t mod[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, col[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  mod[4] = own.x; col[4] = own.y;
+  { const U2 w = word_at(bx, by - 1u); mod[1] = w.x; col[1] = w.y; }
+  { const U2 w = word_at(bx - 1u, by); mod[3] = w.x; col[3] = w.y; }
+  { const U2 w = word_at(bx + 1u, by); mod[5] = w.x; col[5] = w.y; }
+  { const U2 w = word_at(bx, by + 1u); mod[7] = w.x; col[7] = w.y; }
+  __syncthreads();
+  uint32_t C[3][3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const U4 v = pairs[(ly + (uint32_t)r) * (kPvrtcTileW + 2u) + lx + (uint32_t)c];
+      C[r][c][0] = v.x; C[r][c][1] = v.y; C[r][c][2] = v.z; C[r][c][3] = v.w;
+    }
+  uint32_t px[32];
+  decode_pvrtc2_block_expanded(C, mod, col, px);
+  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * P.row_stride + (size_t)bx * 32u;
+#pragma unroll
   for (int y = 0; y < 4; ++y) {
     U4 v0 = { px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3] };
     U4 v1 = { px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7] };
-    *reinterpret_cast<U4 *>(dst + (size_t)y * P.row_stride) = v0;
-    *reinterpret_cast<U4 *>(dst + (size_t)y * P.row_stride + 16) = v1;
+    *reinterpret_cast<U4 *>(dst) = v0;
+    *reinterpret_cast<U4 *>(dst + 16) = v1;
+    dst += P.row_stride;
   }
 }
 }  // extern "C"
@@ -106,6 +168,9 @@ hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_dxt1_decode_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_dxt5_decode_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_etc1_decode_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_PVRTC2 && P.block_cols >= kPvrtcTileW && P.block_rows >= kPvrtcTileH &&
+           (P.block_cols & (P.block_cols - 1u)) == 0u && (P.block_rows & (P.block_rows - 1u)) == 0u)
+    hipLaunchKernelGGL(icamd_pvrtc2_decode_tile_kernel, grid, block, 0, stream, P);  // whole tiles: total_blocks / 256 workgroups
   else if (codec == ICAMD_PVRTC2) hipLaunchKernelGGL(icamd_pvrtc2_decode_kernel, grid, block, 0, stream, P);
   else return hipErrorInvalidValue;
   return hipGetLastError();

@@ -324,18 +324,18 @@ def test_pvrtc_decoder_matches_oracle(pkg):
     oracle's statement of the same rules: encoder output, random block words, a batch, and the 4096^2 size."""
     import torch
     rng = np.random.Generator(np.random.PCG64(31))
-    for n in (8, 16, 32, 128, 512):
+    for n in (8, 16, 32, 128, 256, 512):  # (256^2 and more take the tiled kernel; 256^2 is one tile wide: its ring wraps onto itself)
         cases = [T.oracle_encode(T.PVRTC2, T.GENERATORS[gen](n, n, 4, index=n + 1), n, n, 4) for gen in ("noise", "mixed", "flat")]
         cases.append(rng.integers(0, 256, size=n * n // 4, dtype=np.uint8).tobytes())
         for blocks in cases:
             dec = pkg.decode_device(T.PVRTC2, _dev(np.frombuffer(blocks, np.uint8)), n, n)
             assert _host(dec) == T.oracle_decode(T.PVRTC2, blocks, n, n).tobytes(), n
-    n, k = 64, 5
-    words = rng.integers(0, 256, size=(k, n * n // 4), dtype=np.uint8)
-    dec = pkg.decode_device(T.PVRTC2, _dev(words), n, n, n_images=k)
-    torch.cuda.synchronize()
-    for i in range(k):
-        assert dec[i].cpu().numpy().tobytes() == T.oracle_decode(T.PVRTC2, words[i].tobytes(), n, n).tobytes()
+    for n, k in ((64, 5), (256, 3), (1024, 2)):
+        words = rng.integers(0, 256, size=(k, n * n // 4), dtype=np.uint8)
+        dec = pkg.decode_device(T.PVRTC2, _dev(words), n, n, n_images=k)
+        torch.cuda.synchronize()
+        for i in range(k):
+            assert dec[i].cpu().numpy().tobytes() == T.oracle_decode(T.PVRTC2, words[i].tobytes(), n, n).tobytes(), (n, i)
     n = 4096
     img = T.s_smooth(n, n, 4, index=12)
     enc = pkg.encode_device(T.PVRTC2, _dev(img), n, n, 4)
