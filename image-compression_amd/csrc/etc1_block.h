@@ -357,16 +357,25 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
 }
 
 // FindCodewordHeuristic (etc.cc:415-455): codeword from the largest mean absolute deviation.
+// packed (optional): the sub-block's eight R bytes, G bytes and B bytes as two dwords each ([channel][half], any pixel
+// order) -- the deviation sums are then two v_sad_u8 per channel instead of a v_bfe + v_sad per pixel and channel.
 template <int FLIP, int S>
 ICAMD_DEV EtcSubResult heuristic_codeword(const uint32_t px[16], const EtcBase &base, uint32_t br, uint32_t bg,
-                                          uint32_t bb) {
+                                          uint32_t bb, const uint32_t (*packed)[2] = nullptr) {
   uint32_t sr = 0, sg = 0, sb = 0;
-  ICAMD_UNROLL
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t p = px[sub_pixel<FLIP, S>(j)];
-    sr = sad_u32(br, bfe(p, 0, 8), sr);
-    sg = sad_u32(bg, bfe(p, 8, 8), sg);
-    sb = sad_u32(bb, bfe(p, 16, 8), sb);
+  if (packed) {
+    const uint32_t br4 = br * 0x01010101u, bg4 = bg * 0x01010101u, bb4 = bb * 0x01010101u;  // (<= 255: no carries)
+    sr = sad_u8(packed[0][0], br4, sad_u8(packed[0][1], br4, 0u));
+    sg = sad_u8(packed[1][0], bg4, sad_u8(packed[1][1], bg4, 0u));
+    sb = sad_u8(packed[2][0], bb4, sad_u8(packed[2][1], bb4, 0u));
+  } else {
+    ICAMD_UNROLL
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t p = px[sub_pixel<FLIP, S>(j)];
+      sr = sad_u32(br, bfe(p, 0, 8), sr);
+      sg = sad_u32(bg, bfe(p, 8, 8), sg);
+      sb = sad_u32(bb, bfe(p, 16, 8), sb);
+    }
   }
   const uint32_t dev = umax3(sr >> 3, sg >> 3, sb >> 3);
   const uint32_t cw = (dev > 144u) + (dev > 93u) + (dev > 70u) + (dev > 51u) + (dev > 35u) + (dev > 23u) + (dev > 12u);
@@ -392,7 +401,7 @@ struct EtcFlipResult {
 template <int FLIP, bool TIER = false, bool PRUNE = true, bool SKIP = false>
 ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
                                     const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP,
-                                    bool skip = false) {
+                                    bool skip = false, const uint32_t (*packed)[3][2] = nullptr) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
   uint32_t q5a[3], q5b[3];
   bool diff_mode = true;
@@ -427,8 +436,8 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
   EtcBase e1 = { b1[0] << 24 | b1[2] << 8, b1[1] << 8 };
   EtcSubResult r0, r1;
   if (heuristic) {
-    r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2]);
-    r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2]);
+    r0 = heuristic_codeword<FLIP, 0>(px, e0, b0[0], b0[1], b0[2], packed ? packed[0] : nullptr);
+    r1 = heuristic_codeword<FLIP, 1>(px, e1, b1[0], b1[1], b1[2], packed ? packed[1] : nullptr);
   } else {
     r0 = search_codewords<FLIP, 0, TIER, PRUNE, SKIP>(px, psum, e0, b0, s0, skip);
     r1 = search_codewords<FLIP, 1, TIER, PRUNE, SKIP>(px, psum, e1, b1, s1, skip);
@@ -555,16 +564,36 @@ template <bool TIER = false, bool PRUNE = true, bool SKIP = false>
 ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy, bool skip = false) {
   // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
   uint32_t qs[4][3];
-  ICAMD_UNROLL
-  for (int q = 0; q < 4; ++q) {
-    qs[q][0] = qs[q][1] = qs[q][2] = 0;
+  uint32_t qpk[4][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };  // kHeuristic: the quadrant's four R / G / B bytes
+  if (strategy == 3u) {
+    // kHeuristic is short enough for the sums to matter: a 4 x 3 byte transpose per quadrant (seven v_perm) gives each
+    // channel's four bytes in one dword; a quadrant sum is then ONE v_sad_u8 against 0, and the deviation sums of
+    // FindCodewordHeuristic two v_sad_u8 per channel and sub-block (heuristic_codeword) -- 58 instructions where the
+    // per-pixel forms take 144.
     ICAMD_UNROLL
-    for (int i = 0; i < 4; ++i) {
-      const int y = 2 * (q >> 1) + (i >> 1), x = 2 * (q & 1) + (i & 1);
-      const uint32_t p = px[4 * y + x];
-      qs[q][0] = udot4(p, 0x00000001u, qs[q][0]);
-      qs[q][1] = udot4(p, 0x00000100u, qs[q][1]);
-      qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
+    for (int q = 0; q < 4; ++q) {
+      const int i0 = 8 * (q >> 1) + 2 * (q & 1);
+      const uint32_t p0 = px[i0], p1 = px[i0 + 1], p2 = px[i0 + 4], p3 = px[i0 + 5];
+      const uint32_t t0 = perm(p1, p0, 0x05010400u), t1 = perm(p3, p2, 0x05010400u);  // r r g g
+      const uint32_t t2 = perm(p1, p0, 0x0c0c0602u), t3 = perm(p3, p2, 0x0c0c0602u);  // b b 0 0
+      qpk[q][0] = perm(t1, t0, 0x05040100u);
+      qpk[q][1] = perm(t1, t0, 0x07060302u);
+      qpk[q][2] = perm(t3, t2, 0x05040100u);
+      ICAMD_UNROLL
+      for (int ch = 0; ch < 3; ++ch) qs[q][ch] = sad_u8(qpk[q][ch], 0u, 0u);
+    }
+  } else {
+    ICAMD_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      qs[q][0] = qs[q][1] = qs[q][2] = 0;
+      ICAMD_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        const int y = 2 * (q >> 1) + (i >> 1), x = 2 * (q & 1) + (i & 1);
+        const uint32_t p = px[4 * y + x];
+        qs[q][0] = udot4(p, 0x00000001u, qs[q][0]);
+        qs[q][1] = udot4(p, 0x00000100u, qs[q][1]);
+        qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
+      }
     }
   }
   uint32_t psum[16];  // 2 (r + g + b) per pixel (for the unclamped shortcut)
@@ -616,7 +645,16 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy, bool 
       sa[ch] = flip ? top[ch] : left[ch];
       sb[ch] = flip ? bottom[ch] : right[ch];
     }
-    res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u);
+    // the two sub-blocks' channel bytes: left | right = quadrants (0, 2) | (1, 3), top | bottom = (0, 1) | (2, 3)
+    uint32_t packed[2][3][2];
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      packed[0][ch][0] = qpk[0][ch];
+      packed[0][ch][1] = flip ? qpk[1][ch] : qpk[2][ch];
+      packed[1][ch][0] = flip ? qpk[2][ch] : qpk[1][ch];
+      packed[1][ch][1] = qpk[3][ch];
+    }
+    res = encode_flip<2>(pl, psum, sa, sb, true, flip ? 1u : 0u, false, packed);
     res.score = 0;
   } else {  // kSmallerError (and the reference's default: label)
     const EtcFlipResult r0 = encode_flip<0, TIER, PRUNE, SKIP>(px, psum, left, right, false, 0u, skip);
