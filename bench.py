@@ -549,10 +549,13 @@ def main():
         os.environ.setdefault("LOCAL_RANK", "0")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:  # only when not launched by torch.distributed.run (single forced rank)
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:  # a single forced rank, not launched by torch.distributed.run: any free port will do
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            else:  # ranks started by hand (RANK / WORLD_SIZE set, no launcher) must agree on one port
+                os.environ["MASTER_PORT"] = "29500"
         import datetime
         tmo = datetime.timedelta(seconds=300)  # a wedged collective fails the run instead of hanging it
         if args.backend == "nccl":

@@ -436,7 +436,13 @@ def encode_batch_sharded_device(codec, srcs, height, width, src_components, devi
         assert s.device.index == devices[i % len(devices)], "image %d is not on its listed device" % i
     if gather_device >= 0 and gathered is None:
         gathered = torch.empty((n, per), dtype=torch.uint8, device=torch.device("cuda", gather_device))
-    torch.cuda.synchronize()  # the sources were produced on torch streams; the library uses its own
+    # The sources / outputs were produced on torch streams (and come from torch's caching allocator) on EVERY listed
+    # device, the library uses its own streams: wait for all of them, not just the current device.
+    involved = set(devices[i % len(devices)] for i in range(n))
+    if gather_device >= 0:
+        involved.add(gather_device)
+    for d in sorted(involved):
+        torch.cuda.synchronize(d)
     in_ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
     out_ptrs = None if outs is None else (ctypes.c_void_p * n)(*[(o.data_ptr() if o is not None else None) for o in outs])
     devs = (ctypes.c_int * len(devices))(*devices)

@@ -906,6 +906,8 @@ int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stre
   if (rc != ICAMD_OK) return rc;
   const uint32_t khz = icamd_wall_clock_rate_khz();
   if (khz == 0) return fail(ICAMD_ERR_HIP, "hipDeviceAttributeWallClockRate unavailable");
+  // an exported entry point must not be able to park a wave on the device for an hour (uint32 microseconds = 71 minutes)
+  if (duration_us > ICAMD_CLOCK_PROBE_MAX_US) return fail(ICAMD_ERR_ARG, "clock probe: duration above ICAMD_CLOCK_PROBE_MAX_US (10 s)");
   const uint64_t ticks = (uint64_t)duration_us * khz / 1000u;
   ICAMD_HIP(icamd::launch_clock_probe(static_cast<uint64_t *>(d_out16), ticks, static_cast<hipStream_t>(hip_stream)), "launch clock probe");
   return ICAMD_OK;
@@ -1016,6 +1018,7 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
           continue;
         }
         uint8_t *target = own ? own : scratch;
+        if (codec == ICAMD_PVRTC2) icamd::pvrtc2_select_workspace((int)(run_no & 1u));  // one scratch buffer per stream
         const int rc_run = icamd_encode_device(codec, etc_strategy, src_components, swap_rb, height, width, height, width,
                                                row_stride_bytes, (uint32_t)len, len > 1 ? src_stride : 0,
                                                len > 1 ? (own ? dst_stride : out_size) : 0, d_srcs[i0], target, s);
@@ -1035,6 +1038,7 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
           if (local[mine[j + k]] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
         j += len;
       }
+      icamd::pvrtc2_select_workspace(0);
       const hipError_t e1 = hipStreamSynchronize(st->stream), e2 = hipStreamSynchronize(st->stream2);
       if (e1 != hipSuccess || e2 != hipSuccess) fail_all(ICAMD_ERR_HIP, "stream synchronize failed");
       pool_give(std::move(st));

@@ -76,6 +76,8 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream);
 // launch group), and the thread-local caller-owned override of the library's internal scratch buffer.
 size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images);
 void pvrtc2_set_workspace(void *d_workspace, size_t bytes);
+// this thread's library-owned workspace slot (0 / 1) for the PVRTC launches that follow: one per alternating stream
+void pvrtc2_select_workspace(int slot);
 
 struct DecodeParams {
   const uint8_t *blocks;

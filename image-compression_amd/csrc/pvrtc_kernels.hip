@@ -113,26 +113,34 @@ struct Workspace {
 // Parked workspaces of threads that ended (leaked on purpose at process exit, re-used by later threads).
 std::mutex &g_ws_mutex = *new std::mutex();
 std::vector<Workspace *> &g_ws_parked = *new std::vector<Workspace *>();
+// Two slots per thread: a caller that alternates between two streams (icamd_encode_batch_sharded_device's workers) selects
+// the slot that goes with the stream (pvrtc2_select_workspace), so that a run on one stream does not wait for the previous
+// run on the other through the shared buffer's event.  Slot 0 is the default and the one a caller-owned
+// workspace (icamd_pvrtc2_set_workspace) overrides.
 struct TlsWorkspace {
-  Workspace *p = nullptr;
+  Workspace *p[2] = { nullptr, nullptr };
+  int slot = 0;
   Workspace &get() {
-    if (!p) {
+    Workspace *&w = p[slot];
+    if (!w) {
       std::lock_guard<std::mutex> lock(g_ws_mutex);
       if (!g_ws_parked.empty()) {
-        p = g_ws_parked.back();
+        w = g_ws_parked.back();
         g_ws_parked.pop_back();
       } else {
-        p = new Workspace();
+        w = new Workspace();
       }
     }
-    return *p;
+    return *w;
   }
   ~TlsWorkspace() {
-    if (!p) return;
-    p->user_ptr = nullptr;  // the override was this thread's
-    p->user_bytes = 0;
-    std::lock_guard<std::mutex> lock(g_ws_mutex);
-    g_ws_parked.push_back(p);  // no HIP call here
+    for (Workspace *w : p) {
+      if (!w) continue;
+      w->user_ptr = nullptr;  // the override was this thread's
+      w->user_bytes = 0;
+      std::lock_guard<std::mutex> lock(g_ws_mutex);
+      g_ws_parked.push_back(w);  // no HIP call here
+    }
   }
 };
 thread_local TlsWorkspace g_tls_workspace;
@@ -631,8 +639,12 @@ size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images) {
   if (n_images == 0) return 0;
   return (size_t)((uint64_t)(size / 8) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));
 }
+void pvrtc2_select_workspace(int slot) { g_tls_workspace.slot = slot & 1; }
 void pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
+  const int keep = g_tls_workspace.slot;
+  g_tls_workspace.slot = 0;
   Workspace &ws = g_tls_workspace.get();
+  g_tls_workspace.slot = keep;
   ws.user_ptr = d_workspace;
   ws.user_bytes = d_workspace ? bytes : 0;
 }

@@ -264,7 +264,9 @@ const char *icamd_kernel_name(int codec, int src_components);
 /* ---- diagnostics (measurement aid; not part of the encode path) ----
  * Effective shader clock under load: enqueues ONE wave on hip_stream that sleeps for duration_us and then writes
  * {shader cycles elapsed (s_memtime), constant-rate ticks elapsed (s_memrealtime)} as two uint64 to d_out16.  Run it
- * on a stream of its own next to the kernels being timed; mean clock = cycles / ticks * icamd_wall_clock_rate_khz(). */
+ * on a stream of its own next to the kernels being timed; mean clock = cycles / ticks * icamd_wall_clock_rate_khz().
+ * duration_us above ICAMD_CLOCK_PROBE_MAX_US is refused with ICAMD_ERR_ARG. */
+#define ICAMD_CLOCK_PROBE_MAX_US 10000000u
 int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stream);
 uint32_t icamd_wall_clock_rate_khz(void);  /* hipDeviceAttributeWallClockRate of the current device; 0 if unknown */
 

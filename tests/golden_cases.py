@@ -19,6 +19,11 @@ def load(name):
         return json.load(f)
 
 
+def load_bin(name):
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        return f.read()
+
+
 def check_kats(compress, compress_and_pad):
     """compress(compressor, fmt, src_bytes(np.uint8 1-D), h, w, pad, strategy) -> bytes|None."""
     n = 0

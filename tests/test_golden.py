@@ -53,3 +53,24 @@ def test_oracle_threads_agree():
     img = T.s_noise(128, 64, 4, index=9)
     for codec in (T.DXT1, T.DXT5, T.ETC1):
         assert T.oracle_encode(codec, img, 128, 64, 4, threads=1) == T.oracle_encode(codec, img, 128, 64, 4, threads=5)
+
+
+def test_oracle_decoders_on_arbitrary_block_words_golden():
+    """Seeded random block words (DXT1 3-colour mode, DXT5 6-value alpha, ETC1 differential blocks that leave 0..31)
+    decoded by the reference -> committed hashes."""
+    for c in G.load("random_decode_hashes.json"):
+        blocks = T.random_blocks(c["codec"], c["h"], c["w"], c["seed"])
+        assert hashlib.sha256(blocks).hexdigest() == c["blocks_sha256"], "seeded block generator drifted"
+        px = T.oracle_decode(c["codec"], blocks, c["h"], c["w"], swap=int(c["format"] in (T.BGR, T.BGRA)))
+        assert hashlib.sha256(px.tobytes()).hexdigest() == c["pixels_sha256"], c
+
+
+def test_const_colour_table_pinned():
+    """The one data file the oracle and the product both compile in (dxtc_const_table.inc): its 2 048 values hash to the
+    pinned SHA-256, and -- independently of that file -- the oracle's encoding of every table row equals the bytes the
+    compiled reference produced (tests/golden/solid_ramps_dxt1_*.bin)."""
+    assert hashlib.sha256(T.const_table_bytes()).hexdigest() == T.CONST_TABLE_SHA256
+    img = T.solid_ramp_image()
+    for fmt in (T.RGB, T.BGR):
+        got = T.oracle_compress(T.DXTC, fmt, img.reshape(-1), img.shape[0], img.shape[1])
+        assert got == G.load_bin("solid_ramps_dxt1_%s.bin" % G.FMT_NAMES[fmt])

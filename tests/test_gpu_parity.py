@@ -148,16 +148,21 @@ def test_full_size_dxt1_4096_rgba8_and_rgb888(pkg):
         sub = _host(pkg.encode_device(T.DXT1, _dev(crop), 512, 1024, comps))
         full = np.frombuffer(got, np.uint8).reshape(1024, 1024, 8)
         assert sub == full[128:256, 64:320].tobytes()
+        # kBGR / kBGRA order of the same bytes (R and B swapped at the pixel read, dxtc.cc:288,295,333; const path quirk :360)
+        got_bgr = _host(pkg.encode_device(T.DXT1, _dev(img), h, w, comps, swap_rb=True))
+        assert got_bgr == T.oracle_encode(T.DXT1, img, h, w, comps, swap=1, threads=8)
+        assert got_bgr != got
 
 
 def test_full_size_dxt5_8192(pkg):
     h = w = 8192
     img = T.s_smooth(h, w, 4, index=5)
     img[:2048, :2048] = T.s_noise(2048, 2048, 4, index=5)
-    out = pkg.encode_device(T.DXT5, _dev(img), h, w, 4)
-    got = _host(out)
-    want = T.oracle_encode(T.DXT5, img, h, w, 4, threads=8)
-    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+    for swap in (0, 1):  # kRGBA, kBGRA
+        out = pkg.encode_device(T.DXT5, _dev(img), h, w, 4, swap_rb=bool(swap))
+        got = _host(out)
+        want = T.oracle_encode(T.DXT5, img, h, w, 4, swap=swap, threads=8)
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), swap
 
 
 def test_large_single_image_16384_dxt1(pkg):
@@ -292,6 +297,23 @@ def test_pvrtc_large_batches(pkg):
             assert hashlib.sha256(out[i].cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(want).hexdigest(), (n, size, i)
 
 
+def test_const_colour_table_as_compiled_into_the_library(pkg):
+    """the oracle and the product compile in the SAME dxtc_const_table.inc, so a corrupted table would
+    pass every product-vs-oracle test.  Pin it without the oracle: (1) the file's 2 048 values hash to the pinned SHA-256;
+    (2) the library's encoding of one-colour blocks that read every table row, in both channel widths, equals the bytes
+    the compiled reference produced for them (tests/golden/solid_ramps_dxt1_*.bin), through the device entry point, the
+    host drop-in, and the RGBA8 extension."""
+    assert hashlib.sha256(T.const_table_bytes()).hexdigest() == T.CONST_TABLE_SHA256
+    img = T.solid_ramp_image()
+    h, w = img.shape[:2]
+    rgba = np.concatenate([img, np.full((h, w, 1), 77, np.uint8)], axis=2)
+    for fmt, swap in ((T.RGB, False), (T.BGR, True)):
+        want = G.load_bin("solid_ramps_dxt1_%s.bin" % G.FMT_NAMES[fmt])
+        assert _host(pkg.encode_device(T.DXT1, _dev(img), h, w, 3, swap_rb=swap)) == want
+        assert _host(pkg.encode_device(T.DXT1, _dev(rgba), h, w, 4, swap_rb=swap)) == want
+        assert pkg.compress_host(T.DXTC, fmt, img.reshape(-1), h, w) == want
+
+
 # ---- "next" row 8f.1: decoders
 
 def test_decoders_match_oracle_and_golden(pkg):
@@ -305,14 +327,19 @@ def test_decoders_match_oracle_and_golden(pkg):
         assert hashlib.sha256(_host(blocks)).hexdigest() == c["blocks_sha256"]
         px = pkg.decode_device(codec, blocks.contiguous(), c["h"], c["w"], swap_rb=swap)
         assert hashlib.sha256(_host(px)).hexdigest() == c["pixels_sha256"]
+    # arbitrary block words decoded by the compiled reference -> committed hashes (incl. ETC1 differential blocks that
+    # leave the 5-bit range)
+    for c in G.load("random_decode_hashes.json"):
+        blocks = np.frombuffer(T.random_blocks(c["codec"], c["h"], c["w"], c["seed"]), np.uint8)
+        px = pkg.decode_device(c["codec"], _dev(blocks), c["h"], c["w"], swap_rb=c["format"] in (T.BGR, T.BGRA))
+        assert hashlib.sha256(_host(px)).hexdigest() == c["pixels_sha256"], c
     g = np.random.Generator(np.random.PCG64(11))
     for codec, comps in ((T.DXT1, 3), (T.DXT5, 4), (T.ETC1, 3)):
         for (h, w, pad) in [(64, 64, 0), (13, 7, 0), (9, 9, 5), (1024, 1024, 0)]:
             n = pkg.encoded_size(codec, h, w)
             blocks = g.integers(0, 256, size=n, dtype=np.uint8)
-            if codec == T.ETC1:
-                b = blocks.reshape(-1, 8)
-                b[:, 3] &= 0xFD  # individual mode only: random differential blocks can leave the valid range
+            # (ETC1: random words include differential blocks whose base + delta leaves 0..31 -- the reference's decoder is
+            # fully defined there (Extend5Bit masks, ClampTo8Bits: etc_compressor.cc:198-273) and so is ours)
             want = T.oracle_decode(codec, blocks.tobytes(), h, w, pad=pad)
             got = pkg.decode_device(codec, _dev(blocks), h, w, padding_bytes_per_row=pad)
             torch.cuda.synchronize()

@@ -1,0 +1,90 @@
+"""CPU tier: build-time guards on the generated gfx950 code of kernels whose correctness leans on hand-counted waits.
+
+icamd_pvrtc2_encode_kernel fetches its pixel rows by LDS-DMA and its colour rows from inline asm, with `s_waitcnt vmcnt(4)`
+counted by hand (pvrtc_kernels.hip): the colour registers of block row j >= 2 count as loaded only after the
+third row wait that follows their request.  That holds only while hipcc neither spills those registers nor touches them
+(a v_mov, a use scheduled early) before that wait.  The GPU tier would catch a miscompile as a parity failure; this test
+catches it at build time, on the assembly hipcc emits today: no scratch, and no instruction between the in-loop colour
+loads and the third `s_waitcnt vmcnt(4)` after them names one of their destination registers."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "image-compression_amd", "csrc")
+
+
+def _asm(tu, tmp_path, extra=()):
+    if not shutil.which("hipcc"):
+        pytest.skip("hipcc not available")
+    out = os.path.join(str(tmp_path), "k.s")
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, tu)] + list(extra),
+                          stderr=subprocess.DEVNULL)
+    with open(out) as f:
+        return f.read()
+
+
+def _kernel_meta(text, name):
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:\s+\d+", text, re.S):
+        blk = m.group(0)
+        if re.search(r"\.name:\s+%s\s" % re.escape(name), blk):
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))  # noqa: E731
+            return {"vgprs": g("vgpr_count"), "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")}
+    raise AssertionError("kernel %s not found in the code-object metadata" % name)
+
+
+def _body(text, name):
+    lines = text.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+def _regs(operand_text):
+    """VGPR numbers named in an instruction's operand text: v12, v[12:15]."""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", operand_text))
+    return out
+
+
+def test_pvrtc_encode_kernel_hand_counted_waits_still_hold(tmp_path):
+    text = _asm("pvrtc_kernels.hip", tmp_path)
+    meta = _kernel_meta(text, "icamd_pvrtc2_encode_kernel")
+    assert meta["scratch"] == 0, "icamd_pvrtc2_encode_kernel spills: in-flight colour registers could be stored to scratch"
+    body = _body(text, "icamd_pvrtc2_encode_kernel")
+    loop = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    loads = [i for i in range(loop, len(body)) if re.match(r"\s+global_load_dwordx2\s", body[i])][:3]
+    assert len(loads) == 3 and loads[2] - loads[0] <= 4, "the strip loop's three colour loads were not found together"
+    in_flight = set()
+    for i in loads:
+        in_flight |= _regs(body[i].split("global_load_dwordx2")[1].split(",")[0])
+    assert len(in_flight) == 6
+    waits, checked = 0, 0
+    for l in body[loads[2] + 1:]:
+        if re.match(r"\s+s_waitcnt vmcnt\(0\)", l):
+            continue  # the j <= 1 path waits for everything right away (branched around for j >= 2)
+        if re.match(r"\s+s_waitcnt vmcnt\(4\)", l):
+            waits += 1
+            if waits == 3:
+                break
+            continue
+        m = re.match(r"\s+([a-z_0-9]+)\s+(.*?)(;.*)?$", l)
+        if not m or m.group(1).startswith("s_") or l.strip().startswith((";", ".")):
+            continue
+        touched = _regs(m.group(2)) & in_flight
+        assert not touched, "v%s used before its load is known to have landed: %s" % (sorted(touched), l.strip())
+        checked += 1
+    assert waits == 3 and checked > 300, (waits, checked)
+
+
+def test_pvrtc_register_path_build_still_compiles(tmp_path):
+    """-DICAMD_PVRTC_NO_ROW_DMA (the register path without any hand-counted wait) is the fallback if a compiler change
+    ever breaks the guard above: keep it building and spill-free."""
+    text = _asm("pvrtc_kernels.hip", tmp_path, ["-DICAMD_PVRTC_NO_ROW_DMA"])
+    assert _kernel_meta(text, "icamd_pvrtc2_encode_kernel")["scratch"] == 0

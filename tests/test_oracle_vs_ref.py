@@ -120,6 +120,10 @@ def test_decoders_match():
     assert np.array_equal(T.ref_decompress(T.DXTC, T.RGB, blocks, 64, 64), T.oracle_decode(T.DXT1, blocks, 64, 64))
     blocks = g.integers(0, 256, size=64 * 64 // 16 * 16, dtype=np.uint8).tobytes()
     assert np.array_equal(T.ref_decompress(T.DXTC, T.RGBA, blocks, 64, 64), T.oracle_decode(T.DXT5, blocks, 64, 64))
+    # arbitrary ETC1 words: half of them differential, many with base + delta outside 0..31 (etc_compressor.cc:198-273)
+    for seed in range(8):
+        blocks = T.random_blocks(T.ETC1, 128, 128, 200 + seed)
+        assert np.array_equal(T.ref_decompress(T.ETC, T.RGB, blocks, 128, 128), T.oracle_decode(T.ETC1, blocks, 128, 128))
 
 
 # ---- compressed-domain operations
