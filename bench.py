@@ -22,6 +22,12 @@ After it, for N > 1, a second region of K steps times encode -> RCCL gather of t
 ("wall time from first launch to completion of the RCCL gather on rank 0"), with the gather of batch k on
 a second stream overlapping the encode of batch k+1 -> `value_with_gather`, `gather_ms` (one un-overlapped gather).
 
+`configs` (same line): after the c2 legs the OTHER BASELINE configurations -- c3 (DXT5 8192^2), c4 (ETC1 kSmallerError, 1024 x
+1024^2 over the ranks), c5 (PVRTC 2bpp 4096^2) -- run a handful of timed steps each, with their own roofline and parity.
+`slab` (same line): ONE large image (4096^2 / 8192^2 DXT5 / 16384^2) split into block-row slabs over the ranks
+(sharding.slab_geometry, reference compressor4x4_helper.h:202-214: row-major blocks -> contiguous output ranges), strong
+scaling, plus the gather of the slabs into rank 0's final buffer.  `--shard slab` makes that the headline line instead.
+
 One JSON line is printed by rank 0.  Besides the driver contract it carries
   roofline     -- algorithmic bytes per launch / mean launch duration (HIP events on the launch stream); `bound` says
                   which unit limits the kernel; `hbm_frac` and (where a matching PMC profile is committed) `valu_frac`
@@ -81,12 +87,19 @@ def parse_args(argv=None):
     ap.add_argument("--content", default="noise", choices=["noise", "smooth", "flat"])
     ap.add_argument("--etc-strategy", type=int, default=None)
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the encode->gather region")
+    ap.add_argument("--shard", default="textures", choices=["textures", "slab"],
+                    help="textures: every rank encodes its own textures (weak scaling; c4: strong, texture_range). "
+                         "slab: ONE --size^2 image of the workload split into block-row slabs over the ranks (strong "
+                         "scaling) + gather of the slabs to rank 0")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the c3 / c4 / c5 legs of the default (c2) line")
+    ap.add_argument("--no-slab", action="store_true", help="skip the one-large-image slab legs of the default (c2) line")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra-config / slab leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained-run leg (N = 1)")
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-launch leg (N = 1)")
-    ap.add_argument("--sustained-seconds", type=float, default=2.5)
+    ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--precondition-seconds", type=float, default=1.0,
                     help="untimed back-to-back launches of the step before the W warm-up steps, so that the timed K "
                          "steps see the chip's steady power state rather than its ramp out of idle (0 disables)")
@@ -120,28 +133,34 @@ def relaunch_distributed(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def make_batch(torch, content, batch, size, comps, device, seed):
-    """Synthetic textures generated on the device (integer-only, seeded)."""
-    g = torch.Generator(device=device)
+def make_batch(torch, content, batch, size, comps, device, seed, height=None, row0=0):
+    """Synthetic textures generated on the device (integer-only, seeded): `batch` images of `height` (default: size) rows
+    x `size` columns.  row0: first row of a slab inside its size x size image (only the smooth ramp depends on it)."""
+    h = size if height is None else height
+    if str(device) == "cpu":
+        g = torch.Generator()
+    else:
+        g = torch.Generator(device=device)
     g.manual_seed(0x1234ABCD + seed)
     if content == "noise":
-        return torch.randint(0, 256, (batch, size, size, comps), dtype=torch.uint8, device=device, generator=g)
-    y = torch.arange(size, device=device, dtype=torch.int32).view(1, size, 1)
+        return torch.randint(0, 256, (batch, h, size, comps), dtype=torch.uint8, device=device, generator=g)
+    y = (torch.arange(h, device=device, dtype=torch.int32) + row0).view(1, h, 1)
     x = torch.arange(size, device=device, dtype=torch.int32).view(1, 1, size)
     if content == "smooth":
-        n = torch.randint(0, 32, (batch, size, size), dtype=torch.int32, device=device, generator=g)
+        n = torch.randint(0, 32, (batch, h, size), dtype=torch.int32, device=device, generator=g)
         chans = [(255 * x // size + n) & 255, (255 * y // size + n) & 255, (255 * (x + y) // (2 * size) + n) & 255]
         if comps == 4:
-            a = torch.randint(0, 256, (batch, size, size), dtype=torch.int32, device=device, generator=g)
-            keep = torch.randint(0, 8, (batch, size, size), dtype=torch.int32, device=device, generator=g) != 0
+            a = torch.randint(0, 256, (batch, h, size), dtype=torch.int32, device=device, generator=g)
+            keep = torch.randint(0, 8, (batch, h, size), dtype=torch.int32, device=device, generator=g) != 0
             chans.append(torch.where(keep, torch.full_like(a, 255), a))
         return torch.stack(chans, dim=-1).to(torch.uint8).contiguous()
-    tiles = torch.randint(0, 256, (batch, size // 16, size // 16, comps), dtype=torch.uint8, device=device, generator=g)
+    th = (h + 15) // 16
+    tiles = torch.randint(0, 256, (batch, th, size // 16, comps), dtype=torch.uint8, device=device, generator=g)
     img = tiles.repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)
-    noisy = (torch.randint(0, 8, (batch, size // 16, size // 16, 1), device=device, generator=g) == 0)
+    noisy = (torch.randint(0, 8, (batch, th, size // 16, 1), device=device, generator=g) == 0)
     noisy = noisy.repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)
     noise = torch.randint(0, 256, img.shape, dtype=torch.uint8, device=device, generator=g)
-    return torch.where(noisy, noise, img).contiguous()
+    return torch.where(noisy, noise, img)[:, :h].contiguous()
 
 
 def cpu_baseline(T, codec, comps, size, strategy, host_img):
@@ -332,7 +351,7 @@ class SclkSampler:
 
 
 def sustained_leg(torch, pkg, step_fn, stream, kernel_ms_hint, seconds, algo_bytes):
-    """>= `seconds` of back-to-back launches of the workload (one event between consecutive launches, so a period
+    """>= `seconds` (default 5: long enough for a once-per-second rocm-smi sampler to see the GPU busy) of back-to-back launches of the workload (one event between consecutive launches, so a period
     includes whatever gap the launches leave), with the shader clock measured underneath by a one-wave probe kernel
     on a second stream (s_memtime / s_memrealtime) and the driver-reported sclk sampled from the host.  Reports the
     median period of the first 20 launches, of every later 10 % slice and of the last 20 %."""
@@ -427,6 +446,36 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     per = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     med = _median(per)
     algo = size * size * bytes_per_px
+    # The same calls WITHOUT a timestamp packet pair around each (one event pair around the whole run): r04's kernel trace
+    # (profiles/r04_single_image_timeline.txt) shows the pair itself costs ~2 us per call -- the kernel runs 13.5 us from
+    # dispatch to completion for a 4096^2 DXT1 image either way.  And round-robin over two streams, which is what a caller
+    # with independent textures can do to overlap one call's ramp with the previous call's tail.
+    def run_bare(streams):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        joins = [torch.cuda.Event() for _ in streams[1:]]
+        torch.cuda.synchronize()
+        e0.record(streams[0])
+        for s2 in streams[1:]:
+            s2.wait_event(e0)
+        for i in range(calls):
+            k = i % batch
+            r = pkg.encode_device(codec, src[k], size, size, comps, etc_strategy=strategy, n_images=1, out=out[k:k + 1],
+                                  stream=streams[i % len(streams)])
+            assert r is not None
+        for j, s2 in zip(joins, streams[1:]):
+            j.record(s2)
+            streams[0].wait_event(j)
+        e1.record(streams[0])
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / calls
+        return {"ms_per_call": round(t, 5), "value": round(size * size / (t * 1e-3) / 1e6, 1), "unit": "Mpixels/s",
+                "frac": round(algo / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    bare = two = None
+    try:
+        bare = run_bare([stream])
+        two = run_bare([torch.cuda.Stream(device=src.device), torch.cuda.Stream(device=src.device)])
+    except Exception as e:  # diagnostic legs
+        bare = bare or "unavailable: %s" % e
     # The same calls captured once into a HIP graph (one call per distinct texture) and replayed: what a caller with many
     # single textures gets when the host's per-call launch cost is taken out (PVRTC needs its scratch
     # memory handed over for the capture, icamd_pvrtc2_set_workspace).
@@ -464,7 +513,7 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     except Exception as e:  # a diagnostic leg: never fatal
         graph = "unavailable: %s" % e
     return {
-        "graph_replay": graph,
+        "graph_replay": graph, "back_to_back_no_events": bare, "two_streams_round_robin": two,
         "texture": [size, size], "distinct_textures_rotated": batch, "distinct_source_MiB": distinct_bytes >> 20,
         "calls": calls, "median_ms_per_call": round(med, 5), "min_ms": round(min(per), 5), "max_ms": round(max(per), 5),
         "back_to_back_ms_per_call_wall": round(wall / calls * 1e3, 5),
@@ -516,6 +565,287 @@ def valu_fraction(args, codec, pixels_per_launch, kernel_ms, clock_mhz):
                               "(1024 SIMDs x measured shader clock x sustained kernel time)"}
 
 
+class Ctx:
+    """Rank / world / device of this process and the collectives the legs need.  `sync` is a no-op on the CPU, so that the
+    gloo tier of tests/ can drive the multi-rank legs (with a stand-in encoder) where there is no GPU."""
+
+    def __init__(self, torch, dist, rank, world, device, distributed, backend):
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.distributed, self.backend = distributed, backend
+        self.on_gpu = getattr(device, "type", str(device)) == "cuda"
+
+    def sync(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.distributed:
+            self.dist.barrier()
+
+    def _reduce(self, x, op):
+        if not self.distributed:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64,
+                              device=self.device if (self.backend == "nccl" and self.on_gpu) else "cpu")
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max_over_ranks(self, x):
+        return self._reduce(x, self.dist.ReduceOp.MAX)
+
+    def min_over_ranks(self, x):
+        return self._reduce(x, self.dist.ReduceOp.MIN)
+
+    def sum_over_ranks(self, x):
+        return self._reduce(x, self.dist.ReduceOp.SUM)
+
+    def current_stream(self):
+        return self.torch.cuda.current_stream() if self.on_gpu else None
+
+
+def timed_steps(ctx, step, steps, warmup, precondition_seconds=0.0, stream=None):
+    """The contract's timed region: W warm-up steps, then exactly K steps between barrier + synchronize on both sides.
+    Returns (wall seconds, MAX over ranks; mean ms per step from HIP events on the launch stream -- None on the CPU)."""
+    torch = ctx.torch
+    if precondition_seconds > 0:
+        tp = time.perf_counter()
+        while time.perf_counter() - tp < precondition_seconds:
+            for _ in range(50):
+                step()
+            ctx.sync()
+    for _ in range(warmup):
+        step()
+    ctx.sync()
+    ctx.barrier()
+    ctx.sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if ctx.on_gpu else None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if marks:
+            marks[i].record(stream)
+        step()
+    if marks:
+        marks[steps].record(stream)
+    ctx.sync()
+    ctx.barrier()
+    ctx.sync()
+    elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+    kernel_ms = marks[0].elapsed_time(marks[steps]) / steps if marks else None
+    return elapsed, kernel_ms
+
+
+def preset_traffic(preset, workload, size, batch):
+    """HBM bytes per launch from the committed PMC profile of EXACTLY this launch shape (profiles/traffic.json; FETCH_SIZE
+    and WRITE_SIZE from separate rocprofv3 --pmc passes, scripts/summarize_profiles.py), else None."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as f:
+        t = json.load(f)
+    e = (t.get("presets") or {}).get(preset or "")
+    if e and e.get("workload") == workload and e.get("size") == size and e.get("textures_per_launch") == batch:
+        return e["hbm_bytes_per_launch"], "profiles/traffic.json presets.%s (%s): FETCH_SIZE * 2 + WRITE_SIZE of the committed rocprofv3 " \
+            "--pmc passes of this launch shape (not measured in this run)" % (preset, e.get("profile", "?"))
+    if (size, batch) == (4096, 16) and workload in t:
+        return t[workload], "profiles/traffic.json: FETCH_SIZE * 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes of this " \
+            "workload (not measured in this run)"
+    return None, None
+
+
+def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, gather=True):
+    """One BASELINE configuration other than the headline one, as a compact object for the `configs` field of the line:
+    the same timed region (K steps between barriers, MAX over ranks), roofline of the dominant kernel from HIP events,
+    parity of texture 0 against the oracle, and for N > 1 the gather of the compressed output to rank 0."""
+    torch = ctx.torch
+    cfg = CONFIGS[name]
+    codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[cfg["workload"]]
+    size, strategy = cfg["size"], cfg.get("etc_strategy", 2)
+    if cfg.get("total_textures"):
+        t_begin, t_end = sharding.texture_range(cfg["total_textures"], ctx.world, ctx.rank)
+        batch, scaling = t_end - t_begin, "strong"
+    else:
+        batch, scaling = cfg["batch"], "weak"
+    src = make_batch(torch, content, batch, size, comps, ctx.device, seed=1000 + ctx.rank)
+    per = pkg.encoded_size(codec, size, size)
+    outs = [torch.empty((batch, per), dtype=torch.uint8, device=ctx.device) for _ in range(2)]
+    stream = ctx.current_stream()
+
+    def step(out=None):
+        r = pkg.encode_device(codec, src, size, size, comps, etc_strategy=strategy, n_images=batch,
+                              out=outs[0] if out is None else out, stream=stream)
+        assert r is not None
+    elapsed, kernel_ms = timed_steps(ctx, step, steps, 3, 0.3, stream)
+    px_rank = batch * size * size
+    px_all = ctx.sum_over_ranks(float(px_rank))
+    res = {"workload": "BASELINE config %s: %s" % (name, cfg["text"]), "codec": cfg["workload"], "texture": [size, size],
+           "textures_per_gpu_per_step": batch, "etc_strategy": strategy if codec == 2 else None, "scaling": scaling,
+           "steps": steps, "value": round(px_all * steps / elapsed / 1e6, 1), "unit": "Mpixels/s",
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "data": "synthetic (%s)" % content}
+    if ctx.distributed and gather:
+        try:
+            counts = [e - b for b, e in (sharding.texture_range(cfg["total_textures"], ctx.world, r) for r in range(ctx.world))] \
+                if cfg.get("total_textures") else [batch] * ctx.world
+            res.update(gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, steps, stream, px_all, codec))
+        except Exception as e:
+            res.update({"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)})
+    if ctx.rank == 0:
+        algo = px_rank * bytes_per_px
+        achieved = algo / (kernel_ms * 1e-3) / 1e9
+        traffic, source = preset_traffic(name, cfg["workload"], size, batch)
+        res["roofline"] = {"bound": limiting_unit, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
+                           "kernel": pkg.kernel_name(codec, comps), "kernel_ms": round(kernel_ms, 4),
+                           "algorithmic_bytes_per_launch": int(algo)}
+        if verify:
+            import ic_testlib as T
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+            step(outs[0])
+            ctx.sync()
+            want = T.oracle_encode(codec, src[0].cpu().numpy(), size, size, comps, 0, strategy, threads=1 if codec == 3 else cores)
+            res["parity"] = "bit-exact vs oracle (texture 0 of the batch)" if outs[0][0].cpu().numpy().tobytes() == want \
+                else "MISMATCH vs oracle"
+    del src, outs
+    if ctx.on_gpu:
+        torch.cuda.empty_cache()
+    return res
+
+
+def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_per_step_all, codec):
+    """encode -> gather of the compressed output on rank 0, the gather of batch k on a second stream underneath
+    the encode of batch k + 1 (double-buffered).  step_into(slot) encodes into outs[slot]."""
+    torch = ctx.torch
+    comm = torch.cuda.Stream(device=ctx.device)
+    gathered = [sharding.alloc_gather_buffers(outs[0], counts, ctx.rank) for _ in range(2)]
+    enc_done = [torch.cuda.Event() for _ in range(2)]
+    gat_done = [torch.cuda.Event() for _ in range(2)]
+
+    def gather_async(slot):
+        enc_done[slot].record(stream)
+        with torch.cuda.stream(comm):
+            comm.wait_event(enc_done[slot])
+            sharding.gather_to_root(outs[slot], gathered[slot], counts, ctx.rank, host_staged=ctx.backend == "gloo")
+            gat_done[slot].record(comm)
+
+    for slot in range(2):  # warm-up: communicator set-up, both buffers touched
+        step_into(slot)
+        gather_async(slot)
+    ctx.sync()
+    ctx.barrier()
+    g0 = time.perf_counter()
+    gather_async(0)
+    ctx.sync()
+    ctx.barrier()
+    gather_ms = ctx.max_over_ranks((time.perf_counter() - g0) * 1e3)
+    ctx.sync()
+    ctx.barrier()
+    ctx.sync()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        slot = i & 1
+        stream.wait_event(gat_done[slot])  # the gather that last read this output buffer has finished
+        step_into(slot)
+        gather_async(slot)                 # ... overlaps the encode of the next batch
+    ctx.sync()
+    ctx.barrier()
+    ctx.sync()
+    elapsed_g = ctx.max_over_ranks(time.perf_counter() - t1)
+    ok = True
+    if ctx.rank == 0:
+        last = gathered[(steps - 1) & 1]
+        ok = bool(torch.equal(last[0], outs[(steps - 1) & 1]))
+    out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
+    world = ctx.world
+    return {"value_with_gather": round(pixels_per_step_all * steps / elapsed_g / 1e6, 1),
+            "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4), "gather_ms": round(gather_ms, 4),
+            "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
+            "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, overlapping the "
+                      "next batch's encode (backend %s)" % ctx.backend,
+            "rank0_copy_matches": ok}
+
+
+def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=True, oracle_encode=None):
+    """ONE size x size image split into contiguous slabs of block rows over the ranks (blocks are stored
+    row-major, compressor4x4_helper.h:202-214, so every slab's blocks are one contiguous byte range of the final buffer):
+    strong scaling.  Every rank holds only its slab of the source.  Timed: (1) K encode steps between barriers -> value;
+    (2) K steps of encode -> gather of the slabs into rank 0's final buffer (views of ONE contiguous allocation; equal
+    slabs: one dist.gather, unequal: batched isend / irecv), each step waiting for its gather -> value_with_gather, the
+    latency-shaped figure for one image.  Parity: every rank checks its slab against the oracle's encoding of the same
+    rows (blocks are independent), rank 0 additionally checks the gathered image."""
+    torch = ctx.torch
+    codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[workload]
+    block_bytes = 16 if codec == 1 else 8
+    stride = size * comps
+    geos = [sharding.slab_geometry(size, size, comps, stride, block_bytes, ctx.world, r) for r in range(ctx.world)]
+    geo = geos[ctx.rank]
+    rows, brows, cols = geo["pixel_rows"], geo["block_rows"], (size + 3) // 4
+    src = make_batch(torch, content, 1, size, comps, ctx.device, seed=2000 + ctx.rank, height=max(rows, 4), row0=geo["pixel_row0"])
+    out = torch.empty((max(brows, 1), cols * block_bytes), dtype=torch.uint8, device=ctx.device)[:brows]
+    stream = ctx.current_stream()
+
+    def step():
+        if rows == 0:
+            return
+        r = pkg.encode_device(codec, src, rows, size, comps, n_images=1, out=out.view(1, -1), stream=stream)
+        assert r is not None
+    elapsed, kernel_ms = timed_steps(ctx, step, steps, 3, 0.1, stream)
+    px = float(size) * size
+    res = {"image": [size, size], "codec": workload, "shard": "block-row slabs (sharding.slab_geometry), one per rank",
+           "slab_block_rows": [g["block_rows"] for g in geos], "scaling": "strong", "steps": steps,
+           "value": round(px * steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(elapsed / steps * 1e3, 4)}
+    counts = [g["block_rows"] for g in geos]
+    final = torch.empty((sum(counts), cols * block_bytes), dtype=torch.uint8, device=ctx.device) if ctx.rank == 0 else None
+    bufs = None
+    if ctx.rank == 0:
+        offs = [g["block_row0"] for g in geos]
+        bufs = [final[o:o + c] for o, c in zip(offs, counts)]  # contiguous row ranges of the final image
+    try:
+        def encode_and_gather():
+            step()
+            sharding.gather_to_root(out, bufs, counts, ctx.rank, host_staged=(ctx.backend == "gloo" and ctx.on_gpu))
+        elapsed_g, _ = timed_steps(ctx, encode_and_gather, steps, 2, 0.0, stream)
+        res.update({"value_with_gather": round(px * steps / elapsed_g / 1e6, 1),
+                    "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4),
+                    "gather": "slabs -> rank 0's final buffer (contiguous views), %s, not overlapped: one image's latency"
+                              % ("one rank: device copy" if ctx.world == 1 else "backend " + ctx.backend)})
+    except Exception as e:
+        res.update({"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)})
+    if ctx.rank == 0 and kernel_ms:
+        algo = float(rows) * size * bytes_per_px
+        res["roofline_rank0"] = {"achieved": round(algo / (kernel_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                 "frac": round(algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "kernel_ms": round(kernel_ms, 5)}
+    if verify:
+        ok = 1.0
+        if rows:
+            if oracle_encode is None:
+                import ic_testlib as T
+                cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
+                oracle_encode = lambda a, h, w: T.oracle_encode(codec, a, h, w, comps, threads=max(1, cores // max(1, ctx.world)))  # noqa: E731
+            want = oracle_encode(src[0, :rows].cpu().numpy(), rows, size)
+            ok = 1.0 if out.cpu().numpy().tobytes() == want else 0.0
+            if ctx.rank == 0 and final is not None and ok:
+                ok = 1.0 if final[:brows].cpu().numpy().tobytes() == want else 0.0
+        # the slabs of the OTHER ranks inside rank 0's gathered image: position-weighted byte checksums, compared on rank 0
+        def checksum(t):
+            v = t.reshape(-1).to(torch.int64)
+            return float(((v + 1) * (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1)).sum().item() % (1 << 52))
+        mine = checksum(out) if brows else 0.0
+        if ctx.distributed and res.get("value_with_gather") is not None:
+            sums = torch.zeros(ctx.world, dtype=torch.float64, device=ctx.device if (ctx.backend == "nccl" and ctx.on_gpu) else "cpu")
+            sums[ctx.rank] = mine
+            ctx.dist.all_reduce(sums, op=ctx.dist.ReduceOp.SUM)
+            if ctx.rank == 0:
+                for r in range(ctx.world):
+                    if counts[r] and checksum(bufs[r]) != float(sums[r].item()):
+                        ok = 0.0
+        ok = ctx.min_over_ranks(ok)
+        res["parity"] = "bit-exact vs oracle (every rank's slab); gathered image on rank 0 checked slab by slab (checksums)" \
+            if ok == 1.0 else "MISMATCH"
+    del src, out, final, bufs
+    if ctx.on_gpu:
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -563,9 +893,27 @@ def main():
         else:
             dist.init_process_group(backend="gloo", timeout=tmo)
 
-    def barrier():
+    ctx = Ctx(torch, dist, rank, world, device, distributed, args.backend)
+    barrier = ctx.barrier
+
+    if args.shard == "slab":  # ONE large image over the ranks: the headline line of this mode
+        res = slab_leg(ctx, pkg, sharding, args.workload, args.size, args.steps, args.content, verify=not args.no_verify)
+        if rank == 0:
+            codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[args.workload]
+            tex = "%dx%d %s" % (args.size, args.size, "RGBA8" if comps == 4 else "RGB888")
+            line = {"metric": "Mpixels/s encode (%s, one %s image in block-row slabs)" % (label, tex), "value": res["value"],
+                    "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": 3, "ms_per_step": res["ms_per_step"],
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32",
+                    "data": "synthetic (%s, seeded, generated on device)" % args.content,
+                    "config": {"workload": "%s encode of ONE %s image, block-row slabs over %d rank(s), device-resident" % (label, tex, world),
+                               "codec": args.workload, "texture": [args.size, args.size], "parallelism": res["shard"],
+                               "world_size": world, "visible_gpus": n_dev, "kernel": pkg.kernel_name(codec, comps)}}
+            line.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step", "unit", "steps", "scaling")})
+            print(json.dumps(line))
         if distributed:
             dist.barrier()
+            dist.destroy_process_group()
+        return
 
     codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[args.workload]
     size = args.size
@@ -617,23 +965,9 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = marks[0].elapsed_time(marks[args.steps]) / args.steps
 
-    def max_over_ranks(x):
-        if not distributed:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def sum_over_ranks(x):
-        if not distributed:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item())
-
-    elapsed = max_over_ranks(elapsed)
+    elapsed = ctx.max_over_ranks(elapsed)
     pixels_per_step_rank = batch * size * size
-    pixels_per_step_all = sum_over_ranks(float(pixels_per_step_rank))
+    pixels_per_step_all = ctx.sum_over_ranks(float(pixels_per_step_rank))
     value = pixels_per_step_all * args.steps / elapsed / 1e6
 
     # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
@@ -643,53 +977,8 @@ def main():
             counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
                 else [(r * batch, (r + 1) * batch) for r in range(world)]
             counts = [e - b for b, e in counts]
-            comm = torch.cuda.Stream(device=device)
-            gathered = [sharding.alloc_gather_buffers(outs[0], counts, rank) for _ in range(2)]
-            enc_done = [torch.cuda.Event() for _ in range(2)]
-            gat_done = [torch.cuda.Event() for _ in range(2)]
-
-            def gather_async(slot):
-                enc_done[slot].record(stream)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(enc_done[slot])
-                    sharding.gather_to_root(outs[slot], gathered[slot], counts, rank, host_staged=args.backend == "gloo")
-                    gat_done[slot].record(comm)
-
-            for slot in range(2):  # warm-up: communicator set-up, both buffers touched
-                step(outs[slot])
-                gather_async(slot)
-            torch.cuda.synchronize()
-            barrier()
-            g0 = time.perf_counter()
-            gather_async(0)
-            torch.cuda.synchronize()
-            barrier()
-            gather_ms = max_over_ranks((time.perf_counter() - g0) * 1e3)
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                slot = i & 1
-                stream.wait_event(gat_done[slot])  # the gather that last read this output buffer has finished
-                step(outs[slot])
-                gather_async(slot)                 # ... overlaps the encode of the next batch
-            torch.cuda.synchronize()
-            barrier()
-            torch.cuda.synchronize()
-            elapsed_g = max_over_ranks(time.perf_counter() - t1)
-            ok = True
-            if rank == 0:
-                last = gathered[(args.steps - 1) & 1]
-                ok = bool(torch.equal(last[0], outs[(args.steps - 1) & 1]))
-            out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
-            gather = {"value_with_gather": round(pixels_per_step_all * args.steps / elapsed_g / 1e6, 1),
-                      "ms_per_step_with_gather": round(elapsed_g / args.steps * 1e3, 4),
-                      "gather_ms": round(gather_ms, 4),
-                      "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
-                      "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, "
-                                "overlapping the next batch's encode (backend %s)" % args.backend,
-                      "rank0_copy_matches": ok}
+            gather = gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, args.steps, stream,
+                                   pixels_per_step_all, codec)
         except Exception as e:  # the encode-only line must survive a failing gather (it is reported, not hidden)
             gather = {"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)}
 
@@ -708,6 +997,7 @@ def main():
                    "texture": [size, size], "src_bytes_per_pixel": comps,
                    "etc_strategy": args.etc_strategy if codec == 2 else None,
                    "parallelism": "independent textures per GPU, texture_range per rank (no data-path collective)",
+                   "world_size": dist.get_world_size() if distributed else 1, "visible_gpus": n_dev,
                    "kernel": pkg.kernel_name(codec, comps)},
     }
     if gather is not None:
@@ -716,11 +1006,7 @@ def main():
     if rank == 0:
         algo_bytes = pixels_per_step_rank * bytes_per_px
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and (size, batch) == (4096, 16):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.workload)
+        traffic, traffic_source = preset_traffic(args.preset, args.workload, size, batch)
         hbm_frac = round(achieved / HBM_PEAK_GBPS, 4)
         result["roofline"] = {
             "bound": limiting_unit, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -729,8 +1015,7 @@ def main():
             "algorithmic_bytes_per_pixel": bytes_per_px, "algorithmic_bytes_per_launch": int(algo_bytes),
             "read_roofline_frac": round((pixels_per_step_rank * comps / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS, 4),
         }
-        result["roofline"]["traffic_source"] = None if traffic is None else \
-            "profiles/traffic.json: FETCH_SIZE * 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes of this workload (not measured in this run)"
+        result["roofline"]["traffic_source"] = traffic_source
         import ic_testlib as T
         host0 = src[0].cpu().numpy()
         if not args.no_verify:
@@ -783,6 +1068,30 @@ def main():
                 result["single_image"] = "unavailable: %s: %s" % (type(e).__name__, e)
         result["library"] = {"path": os.path.relpath(pkg.LIB_PATH, ROOT), "overridden": bool(pkg.LIB_OVERRIDDEN),
                              "version": pkg.lib().icamd_version().decode()}
+    # ---- the other BASELINE configurations and the one-large-image slab legs, in the same line (every rank takes part).
+    # Only the default line (preset c2, no overrides) carries them; each leg frees its buffers before the next.
+    default_line = args.preset == "c2" and args.content == "noise"
+    if default_line and not (args.no_extra_configs and args.no_slab):
+        del src, outs
+        torch.cuda.empty_cache()
+        if not args.no_extra_configs:
+            configs = {}
+            for name in ("c3", "c4", "c5"):
+                try:
+                    configs[name] = preset_leg(ctx, pkg, sharding, name, args.extra_steps, verify=not args.no_verify,
+                                               gather=not args.no_gather)
+                except Exception as e:  # a failing extra leg is reported, it does not take the headline down
+                    configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            result["configs"] = configs
+        if not args.no_slab:
+            slabs = {}
+            for key, wl, sz in (("c2_one_4096", "dxt1_rgba8", 4096), ("c3_one_8192", "dxt5_rgba8", 8192), ("one_16384", "dxt1_rgba8", 16384)):
+                try:
+                    slabs[key] = slab_leg(ctx, pkg, sharding, wl, sz, args.extra_steps, verify=not args.no_verify)
+                except Exception as e:
+                    slabs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+            result["slab"] = slabs
+    if rank == 0:
         print(json.dumps(result))
     if distributed:
         dist.barrier()

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -952,8 +953,11 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
       if (gather && dev != gather_device) {
         // direct xGMI copies into the gather buffer: without peer access hipMemcpyPeerAsync bounces through host memory.
         // Best effort -- "already enabled" and "not supported" both leave a working (if slower) copy path.
+        // (ICAMD_DISABLE_PEER_ACCESS=1: test knob -- take the host-bounced copy path on a box that has peer access)
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, dev, gather_device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(gather_device, 0);
+        const char *no_peer = getenv("ICAMD_DISABLE_PEER_ACCESS");
+        if (!(no_peer && no_peer[0] == '1') && hipDeviceCanAccessPeer(&can, dev, gather_device) == hipSuccess && can)
+          (void)hipDeviceEnablePeerAccess(gather_device, 0);
         (void)hipGetLastError();
       }
       std::unique_ptr<Staging> st = pool_take(dev);

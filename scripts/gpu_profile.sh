@@ -15,7 +15,7 @@ rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 WLS=${@:-dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8}
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
-COMMON="--no-cpu-baseline --no-verify --no-host-api --no-sustained --no-single-image"
+COMMON="--no-cpu-baseline --no-verify --no-host-api --no-sustained --no-single-image --no-extra-configs --no-slab"
 for wl in $WLS; do
   T="python bench.py --steps 100 --warmup 5 --precondition-seconds 0.5 --workload $wl $COMMON"
   B="python bench.py --steps 20 --warmup 3 --precondition-seconds 0 --workload $wl $COMMON"
@@ -36,6 +36,15 @@ case " $WLS " in *" etc1_rgb888 "*)
       python bench.py --steps 20 --warmup 3 --precondition-seconds 0 --workload etc1_rgb888 --etc-strategy $s $COMMON > "$O/$tag.sq.log" 2>&1
   done;;
 esac
+# HBM traffic of the BASELINE presets whose launch shape differs from the workload defaults (c3: 4 x 8192^2 DXT5, c4: 1024 x
+# 1024^2 ETC1 kSmallerError): FETCH_SIZE / WRITE_SIZE in separate passes -> profiles/traffic.json "presets"
+if [ -z "${SKIP_PRESETS:-}" ]; then
+  for cfg in c3 c4; do
+    B="python bench.py --steps 10 --warmup 2 --precondition-seconds 0 --config $cfg $COMMON"
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/preset_$cfg/pmc_fetch" -o "preset_$cfg" -- $B > "$O/preset_$cfg.fetch.log" 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/preset_$cfg/pmc_write" -o "preset_$cfg" -- $B > "$O/preset_$cfg.write.log" 2>&1
+  done
+fi
 # keep the merge small: the raw kernel traces of the preconditioned runs are reduced to per-launch duration lists
 python - <<'PY'
 import csv, glob, os

@@ -12,6 +12,7 @@ import json
 import os
 import sys
 
+csv.field_size_limit(1 << 30)  # torch's kernel names run to several KiB
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
@@ -35,7 +36,7 @@ def main():
     per_step = {}
     for wl in sorted(os.listdir(SRC)):
         d = os.path.join(SRC, wl)
-        if not os.path.isdir(d):
+        if not os.path.isdir(d) or wl.startswith("preset_"):
             continue
         stats_csv = os.path.join(d, "trace", wl + "_kernel_stats.csv")
         if not os.path.exists(stats_csv):
@@ -98,6 +99,24 @@ def main():
                               for k, e in summary["kernels"].items()})[:600])
     for wl, b in per_step.items():  # bytes per bench step (= per launch for the single-kernel workloads)
         traffic[wl] = int(b)
+    # per BASELINE preset (bench.py's `configs` legs look their launch shape up here): c2 / c5 have the workload passes'
+    # shape (16 x 4096^2); c3 / c4 come from their own passes (gpurun_out/prof/preset_cN)
+    presets = traffic.setdefault("presets", {})
+    shapes = {"c2": ("dxt1_rgba8", 4096, 16), "c3": ("dxt5_rgba8", 8192, 4), "c4": ("etc1_rgb888", 1024, 1024),
+              "c5": ("pvrtc2_rgba8", 4096, 16)}
+    for cfg, (wl, size, n) in shapes.items():
+        if cfg in ("c2", "c5"):
+            if wl in per_step:
+                presets[cfg] = {"workload": wl, "size": size, "textures_per_launch": n, "hbm_bytes_per_launch": int(per_step[wl]),
+                                "profile": "%s, bench.py --workload %s" % (rnd, wl)}
+            continue
+        d = os.path.join(SRC, "preset_" + cfg)
+        fetch = counters(os.path.join(d, "pmc_fetch", "preset_%s_counter_collection.csv" % cfg))
+        write = counters(os.path.join(d, "pmc_write", "preset_%s_counter_collection.csv" % cfg))
+        total = sum(v * 2048 for (k, c), v in fetch.items() if c == "FETCH_SIZE") + sum(v * 1024 for (k, c), v in write.items() if c == "WRITE_SIZE")
+        if total > 0:
+            presets[cfg] = {"workload": wl, "size": size, "textures_per_launch": n, "hbm_bytes_per_launch": int(total),
+                            "profile": "%s, bench.py --config %s" % (rnd, cfg)}
     with open(tpath, "w") as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     # executed VALU instructions per workload / content / ETC strategy: what bench.py's roofline.valu_frac is built on
@@ -107,7 +126,7 @@ def main():
     mpix = 16 * 4096 * 4096 / 1e6  # pixels of one bench step
     for tag in sorted(os.listdir(SRC)):
         d = os.path.join(SRC, tag)
-        if not os.path.isdir(d):
+        if not os.path.isdir(d) or tag.startswith("preset_"):
             continue
         wl, content, strat = (tag.split("__") + ["noise", "s2"])[:3] if "__" in tag else (tag, "noise", "s2")
         sq = counters(os.path.join(d, "pmc_sq", tag + "_counter_collection.csv"))

@@ -712,27 +712,30 @@ def test_bench_bare_command_self_launches_ranks(pkg):
 
 def test_bench_config_presets(pkg):
     for cfg, codec, size in (("c3", "dxt5_rgba8", 8192), ("c5", "pvrtc2_rgba8", 4096)):
-        d = _run_bench(["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-api"])
+        d = _run_bench(["--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-api",
+                        "--sustained-seconds", "0.5"])
         assert d["config"]["codec"] == codec and d["config"]["texture"] == [size, size] and d["config"]["preset"] == cfg
         assert d["parity"].startswith("bit-exact") and d["roofline"]["bound"] == "valu"
 
 
-def test_nccl_sharded_encode_and_gather_on_real_gpus(pkg):
-    """World size >= 2 over RCCL with the HIP encoder (skipped on a 1-GPU box): every rank encodes its texture_range
-    of a shared batch on its own GPU, gather_to_root assembles the output on rank 0, compared with the oracle."""
-    import os
-    import subprocess
-    import sys
-    import torch
-    n_dev = torch.cuda.device_count()
-    if n_dev < 2:
-        pytest.skip("needs >= 2 GPUs (the pool's boxes have one)")
-    world = min(n_dev, 4)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-                        "--master-addr", "127.0.0.1", "--master-port", "29641",
-                        os.path.join(T.ROOT, "tests", "nccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
-    assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg):
+    """The line the driver records (bench.py with no --config): c2 headline + `configs` {c3, c4, c5} + `slab` (one 4096^2 /
+    8192^2 / 16384^2 image in block-row slabs, gathered into rank 0's final buffer), each with its own parity; and the
+    slab mode as a headline line, over the RCCL code path with one forced rank."""
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--extra-steps", "2", "--no-sustained", "--no-single-image", "--no-host-api",
+                    "--no-cpu-baseline", "--precondition-seconds", "0"], timeout=900)
+    assert d["config"]["preset"] == "c2" and d["parity"].startswith("bit-exact")
+    assert sorted(d["configs"]) == ["c3", "c4", "c5"]
+    for name, leg in d["configs"].items():
+        assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, (name, leg)
+    assert d["configs"]["c4"]["textures_per_gpu_per_step"] == 1024 and d["configs"]["c4"]["etc_strategy"] == 2
+    assert d["configs"]["c5"]["roofline"]["traffic"] and d["roofline"]["traffic"]
+    for name, leg in d["slab"].items():
+        assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
+    d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--shard", "slab", "--workload", "dxt5_rgba8",
+                    "--size", "8192", "--steps", "3"])
+    assert d["scaling"] == "strong" and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
+    assert d["config"]["world_size"] == 1 and d["slab_block_rows"] == [2048]
 
 
 def test_rccl_code_path_executes_with_a_single_rank(pkg):
@@ -756,16 +759,57 @@ def test_rccl_code_path_executes_with_a_single_rank(pkg):
     assert "backend nccl" in d["gather"]
 
 
-def test_single_process_batch_on_distinct_devices(pkg):
+def test_every_inter_gpu_path_on_a_multi_gpu_box(pkg):
+    """The ONE test that needs >= 2 GPUs (the pool's boxes have one; every path below also has a 1-GPU / gloo twin that
+    runs everywhere).  On the first multi-GPU box it exercises, in one go:
+      1. RCCL, one rank per GPU (tests/nccl_worker.py): texture_range sharding, dist.gather with equal counts, the batched
+         isend / irecv gather with UNEQUAL counts (n = 4 world + 1), all_gather_into_tensor;
+      2. icamd_compress_batch on distinct devices (host buffers, one worker thread per device);
+      3. icamd_encode_batch_sharded_device on distinct devices: hipMemcpyPeerAsync into the gather buffer with peer access
+         enabled (default) and refused (ICAMD_DISABLE_PEER_ACCESS=1, a fresh process: peer access is sticky);
+      4. bench.py --gpus 2 as the driver launches it: headline + c3 / c4 / c5 legs + the one-large-image slab legs with their
+         gathers, parity asserted in every leg."""
+    import os
+    import subprocess
+    import sys
     import torch
     n_dev = torch.cuda.device_count()
     if n_dev < 2:
         pytest.skip("needs >= 2 GPUs (the pool's boxes have one)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for world, port in ((min(n_dev, 4), 29641), (min(n_dev, 3), 29645)):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join(T.ROOT, "tests", "nccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (world, p.stdout[-3000:], p.stderr[-3000:])
+    # 2
     n, h, w = 11, 200, 264
     imgs = [T.s_mixed(h, w, 3, index=i) for i in range(n)]
     want = [T.oracle_compress(T.ETC, T.RGB, im, h, w) for im in imgs]
     assert pkg.compress_batch_host(T.ETC, T.RGB, imgs, h, w, list(range(n_dev))) == want
     assert pkg.compress_batch_host(T.ETC, T.RGB, imgs, h, w, [n_dev - 1, 0]) == want
+    # 3 (peer access refused first, in its own process; then enabled, here)
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n" \
+           "import torch, ic_amd_loader, test_gpu_parity as G\npkg = ic_amd_loader.load_package()\n" \
+           "G._sharded_case(pkg, pkg.DXT1, 4, 512, 2 * torch.cuda.device_count() + 1, list(range(torch.cuda.device_count())))\n" \
+           "print('NO_PEER_OK')" % (T.ROOT, os.path.join(T.ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(env, ICAMD_DISABLE_PEER_ACCESS="1"))
+    assert p.returncode == 0 and "NO_PEER_OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    devices = list(range(n_dev))
+    _sharded_case(pkg, pkg.DXT1, 4, 512, 2 * len(devices) + 1, devices)
+    _sharded_case(pkg, pkg.ETC1, 3, 256, len(devices) + 1, devices)
+    _sharded_case(pkg, pkg.PVRTC2, 4, 256, len(devices) + 2, devices)
+    # 4
+    d = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--extra-steps", "2", "--no-sustained", "--no-single-image",
+                    "--no-host-api", "--no-cpu-baseline", "--precondition-seconds", "0"], timeout=1200)
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["rank0_copy_matches"] is True
+    for name, leg in d["configs"].items():
+        assert leg.get("parity", "").startswith("bit-exact") and leg.get("rank0_copy_matches") is True, (name, leg)
+    for name, leg in d["slab"].items():
+        assert leg.get("parity", "").startswith("bit-exact") and leg.get("value_with_gather"), (name, leg)
+    d = _run_bench(["--gpus", "2", "--shard", "slab", "--workload", "dxt5_rgba8", "--size", "8192", "--steps", "3"], timeout=600)
+    assert d["scaling"] == "strong" and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
 
 
 # ---- geometries beyond one launch's limits (chunked inside the library; the reference accepts any uint32 size)
@@ -982,15 +1026,6 @@ def test_sharded_device_batch_of_evenly_spaced_images(pkg):
             st, _, _ = pkg.encode_batch_sharded_device(codec, srcs2, size, size, comps, devices, outs=[out[i] for i in range(n)])
             o = out.cpu().numpy()
             assert st == [0] * n and all(o[i].tobytes() == want[i] for i in range(n)), (codec, devices, "split runs")
-
-
-def test_sharded_device_batch_on_distinct_gpus(pkg):
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs >= 2 GPUs (hipMemcpyPeerAsync over xGMI)")
-    devices = list(range(torch.cuda.device_count()))
-    _sharded_case(pkg, pkg.DXT1, 4, 512, 2 * len(devices) + 1, devices)
-    _sharded_case(pkg, pkg.ETC1, 3, 256, len(devices) + 1, devices)
 
 
 def test_pvrtc_workspace_must_be_device_memory(pkg):

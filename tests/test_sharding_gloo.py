@@ -159,3 +159,64 @@ def test_pvrtc_regions_partition_the_block_grid():
     import pytest
     with pytest.raises(ValueError):
         sh.pvrtc_region(64, 3, 0)
+
+
+# ---- bench.py's one-large-image slab mode (strong scaling + gather into rank 0's final buffer) over gloo, with the
+# oracle standing in for the device encoder (tests only): every rank's slab and the gathered image must check out.
+
+class _OraclePkg:
+    """The two entry points bench.slab_leg uses, backed by the oracle on CPU tensors."""
+
+    @staticmethod
+    def encoded_size(codec, h, w):
+        return int(T.oracle().ico_encoded_size(codec, h, w))
+
+    @staticmethod
+    def kernel_name(codec, comps):
+        return "oracle-stand-in"
+
+    @staticmethod
+    def encode_device(codec, src, height, width, comps, *, n_images=1, out=None, stream=None, etc_strategy=2, **kw):
+        assert n_images == 1 and not src.is_cuda
+        got = T.oracle_encode(codec, src.numpy().reshape(-1)[:height * width * comps], height, width, comps, 0, etc_strategy)
+        out.view(-1)[:len(got)].copy_(torch.from_numpy(np.frombuffer(got, np.uint8).copy()))
+        return out
+
+
+def _slab_worker(rank, world, port, results):
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, T.ROOT)
+    import bench
+    sh = _load_sharding()
+    ctx = bench.Ctx(torch, dist, rank, world, torch.device("cpu"), True, "gloo")
+    ok = True
+    for workload, size, content in (("dxt1_rgba8", 64, "noise"), ("dxt5_rgba8", 40, "smooth"), ("dxt1_rgb888", 12, "flat")):
+        res = bench.slab_leg(ctx, _OraclePkg, sh, workload, size, 2, content)
+        ok &= res["parity"].startswith("bit-exact") and res.get("value_with_gather") is not None and res["scaling"] == "strong"
+        ok &= sum(res["slab_block_rows"]) == (size + 3) // 4
+    # a corrupted encoder must be caught by the slab check
+    class Bad(_OraclePkg):
+        @staticmethod
+        def encode_device(*a, **kw):
+            out = _OraclePkg.encode_device(*a, **kw)
+            if rank == world - 1:
+                out.view(-1)[0] ^= 1
+            return out
+    res = bench.slab_leg(ctx, Bad, sh, "dxt1_rgba8", 64, 1, "noise")
+    ok &= res["parity"].startswith("MISMATCH")
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    results[rank] = int(flag.item())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])  # 3: unequal slab heights -> the batched isend / irecv gather
+def test_bench_slab_mode_over_gloo(world):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_slab_worker, args=(world, port, results), nprocs=world, join=True)
+        assert dict(results) == {r: 1 for r in range(world)}
