@@ -442,7 +442,8 @@ def encode_batch_sharded_device(codec, srcs, height, width, src_components, devi
     if gather_device >= 0:
         involved.add(gather_device)
     for d in sorted(involved):
-        torch.cuda.synchronize(d)
+        if 0 <= d < torch.cuda.device_count():  # (a bad ordinal is the C side's to refuse, with its own status)
+            torch.cuda.synchronize(d)
     in_ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
     out_ptrs = None if outs is None else (ctypes.c_void_p * n)(*[(o.data_ptr() if o is not None else None) for o in outs])
     devs = (ctypes.c_int * len(devices))(*devices)
