@@ -36,7 +36,7 @@ EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
+    "icamd_downsample", "icamd_downsample_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
     "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
@@ -92,6 +92,9 @@ def lib():
         L.icamd_downsample.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _vp, _sz]
         L.icamd_downsample_device.restype = _ci
         L.icamd_downsample_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _vp, _vp, _sz, _vp]
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_downsample_batch_device"):  # r04 entry point
+            L.icamd_downsample_batch_device.restype = _ci
+            L.icamd_downsample_batch_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _sz, _vp, _sz, _sz, _vp]
         L.icamd_transcode_dxt1_to_etc1.restype = _ci
         L.icamd_transcode_dxt1_to_etc1.argtypes = [_vp, _sz]
         L.icamd_transcode_dxt1_to_etc1_device.restype = _ci
@@ -283,6 +286,20 @@ def downsample_host(compressor, fmt, blocks, height, width, etc_strategy=ETC_SMA
     out = np.zeros(max(n, 1), np.uint8)
     st = lib().icamd_downsample(compressor, etc_strategy, fmt, height, width, b.ctypes.data, out.ctypes.data, n)
     return out[:n].tobytes() if _check(st, "icamd_downsample") else None
+
+
+def downsample_device(compressor, fmt, blocks, height, width, *, etc_strategy=ETC_SMALLER_ERROR, n_images=1, stream=None):
+    """Compressor::Downsample on device-resident block grids: `blocks` = torch.uint8 CUDA tensor [n_images, bytes of one
+    height x width image] (contiguous); returns [n_images, bytes of the halved image] or None where the reference refuses."""
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+    dh, dw = (height + 1) // 2, (width + 1) // 2
+    per_out = ((dh + 3) // 4) * ((dw + 3) // 4) * _block_bytes(compressor, fmt)
+    per_in = blocks.numel() // n_images
+    out = torch.empty((n_images, per_out), dtype=torch.uint8, device=blocks.device)
+    st = lib().icamd_downsample_batch_device(compressor, etc_strategy, fmt, height, width, n_images,
+                                             ctypes.c_void_p(blocks.data_ptr()), per_in, ctypes.c_void_p(out.data_ptr()),
+                                             per_out, per_out, _stream_handle(stream))
+    return out if _check(st, "icamd_downsample_batch_device") else None
 
 
 def transcode_dxt1_to_etc1_host(blocks):

@@ -73,6 +73,209 @@ ICAMD_DEV void store_downsampled(const uint32_t src[16], int tr, int tc, uint32_
   }
 }
 
+// ---- DownsampleBlocks2x2 of DXT blocks without ever materialising the 64 source pixels (r04) ------------------------
+// A DXT colour block holds at most four colours.  Keep the palette as three "planes" -- byte k of P[ch] = channel ch of
+// palette entry k -- and the four 2-bit indices of a 2x2 pixel quad as the four bytes of a selector: ONE v_perm_b32 then
+// yields the quad's four values of a channel, and their sum is one v_sad_u8 / v_dot4.  Per output pixel that is
+// 4 (selector) + 3 x 2 (perm + sum) + 4 (pack) instructions instead of four 4-way palette look-ups and a 14-instruction
+// average -- bit-exact with DecodeDxt1Block / DecodeDxt5Block (dxtc.cc:167-267) followed by Average4ColorsFast
+// (color_util.h:335-380): (a + b + c + d) / 4 per channel, truncating.
+//
+// Palette planes of the colour block whose first dword is w0 (c0 | c1 << 16).  always4 = DXT5's colour block.
+ICAMD_DEV void dxt_palette_planes(uint32_t w0, bool always4, uint32_t P[3]) {
+  // ExtendToRgb888 (color_util.h:232-236) on both endpoints at once: X0 | X1 << 16 per channel
+  const uint32_t r = (w0 >> 11) & 0x001f001fu, g = (w0 >> 5) & 0x003f003fu, b = w0 & 0x001f001fu;
+  const uint32_t X[3] = { (r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2) };
+  const uint32_t c0 = w0 & 0xffffu, c1 = w0 >> 16;
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    const uint32_t x0 = X[ch] & 0xffu, x1 = bfe(X[ch], 16, 8);  // (the right shifts leak endpoint 1's low bits into bits 8-15)
+    // (2 a + b) / 3 and (a + 2 b) / 3 (CombineUint8Fast, color_util.h:288-291); c0 == c1 gives x2 = x3 = x1, which is
+    // what the decoder's special case for equal endpoints produces (dxtc.cc:184-186)
+    const uint32_t x2 = div3(umad24(x0, 2u, x1)), x3 = div3(umad24(x1, 2u, x0));
+    P[ch] = x0 | x1 << 8 | x2 << 16 | x3 << 24;
+  }
+  // DXT1's three-colour mode (c0 < c1): entry 2 = (a + b) / 2, entry 3 = black (dxtc.cc:187-193).  Our own encoder emits
+  // it only from the constant-colour path; a wave without such a block skips this.
+  if (!always4 && !wave_all(c0 >= c1)) {
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      const uint32_t x0 = X[ch] & 0xffu, x1 = bfe(X[ch], 16, 8);
+      const uint32_t alt = x0 | x1 << 8 | ((x0 + x1) >> 1) << 16;
+      P[ch] = c0 < c1 ? alt : P[ch];
+    }
+  }
+}
+
+// t: the index bytes of two pixel rows at bits 0-7 and 16-23 (2 bits per pixel).  Returns the selector of the 2x2 quad
+// at columns 2 QX, 2 QX + 1: byte i = index of quad pixel i (order: row 0 left, right, row 1 left, right).
+template <int QX>
+ICAMD_DEV uint32_t dxt_quad_selector(uint32_t t) {
+  const uint32_t v = (QX ? t >> 4 : t) & 0x000f000fu;  // the two rows' nibbles
+  return (v | v << 6) & 0x03030303u;                    // nibble = (hi2 << 2 | lo2): lo2 stays, hi2 moves up one byte
+}
+
+// Sum / 4 of the quad's four palette entries, packed R | G << 8 | B << 16 (byte 3 = 0).
+ICAMD_DEV uint32_t dxt_quad_average(const uint32_t P[3], uint32_t sel) {
+  const uint32_t sr = sad_u8(perm(P[0], P[0], sel), 0u, 0u);
+  const uint32_t tg = udot4(perm(P[1], P[1], sel), 0x40404040u, 0u);  // 64 * sum: (sum / 4) << 8 after masking
+  const uint32_t tb = udot4(perm(P[2], P[2], sel), 0x40404040u, 0u);
+  return ((tb & 0xff00u) << 8) | (tg & 0xff00u) | (sr >> 2);
+}
+
+// The eight alpha values of a DXT5 alpha block (first dword w0 = a0 | a1 << 8 | codes...) as two dwords of bytes
+// (DecodeAlphaValues, dxtc.cc:195-217).
+ICAMD_DEV void dxt5_alpha_planes(uint32_t w0, uint32_t &tlo, uint32_t &thi) {
+  const uint32_t a0 = w0 & 0xffu, a1 = (w0 >> 8) & 0xffu;
+  const bool eight = a0 > a1;
+  uint32_t lo8 = 0, hi8 = 0, lo6 = 0, hi6 = 0;
+  if (!wave_all(!eight)) {  // some lane interpolates six values in sevenths
+    uint32_t t[8];
+    t[0] = a0; t[1] = a1;
+    ICAMD_UNROLL
+    for (int k = 1; k <= 6; ++k) t[1 + k] = div7(umad24(a0, (uint32_t)(7 - k), umad24(a1, (uint32_t)k, 0u)));
+    lo8 = t[0] | t[1] << 8 | t[2] << 16 | t[3] << 24;
+    hi8 = t[4] | t[5] << 8 | t[6] << 16 | t[7] << 24;
+  }
+  if (!wave_all(eight)) {   // some lane interpolates four values in fifths, then 0 and 255
+    uint32_t t[6];
+    t[0] = a0; t[1] = a1;
+    ICAMD_UNROLL
+    for (int k = 1; k <= 4; ++k) t[1 + k] = div5(umad24(a0, (uint32_t)(5 - k), umad24(a1, (uint32_t)k, 0u)));
+    lo6 = t[0] | t[1] << 8 | t[2] << 16 | t[3] << 24;
+    hi6 = t[4] | t[5] << 8 | 0xff000000u;  // t[6] = 0, t[7] = 255
+  }
+  tlo = eight ? lo8 : lo6;
+  thi = eight ? hi8 : hi6;
+}
+
+// h24: the 3-bit alpha codes of two pixel rows (pixels 0..7 of the pair, 24 bits).  Selector of the quad at columns
+// 2 QX, 2 QX + 1: byte i = code (0..7) of quad pixel i -- v_perm_b32 over {thi, tlo} looks all four alphas up at once.
+template <int QX>
+ICAMD_DEV uint32_t dxt5_quad_alpha_selector(uint32_t h24) {
+  const uint32_t x = QX ? h24 >> 6 : h24;
+  const uint32_t y = (x & 0x3fu) | bfe(x, 12, 6) << 16;  // codes (0, 1) at bits 0-5, (2, 3) at bits 16-21
+  return (y | y << 5) & 0x07070707u;
+}
+
+// px[16] <- the 2x2 averages of the 8x8 pixels that the four blocks s[i][j] (i = block row, j = block column; 2 or 4
+// dwords each) decode to.  CODEC: ICAMD_DXT1 / ICAMD_DXT5 numbering of ic_amd.h (0 / 1).
+template <int CODEC>
+ICAMD_DEV void dxt_downsample_2x2(const uint32_t *const s[2][2], uint32_t px[16]) {
+  ICAMD_UNROLL
+  for (int i = 0; i < 2; ++i) {
+    ICAMD_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t *w = s[i][j];
+      const uint32_t cw0 = CODEC == 1 ? w[2] : w[0], bits = CODEC == 1 ? w[3] : w[1];
+      uint32_t P[3];
+      dxt_palette_planes(cw0, CODEC == 1, P);
+      uint32_t tlo = 0, thi = 0, lo24 = 0, hi24 = 0;
+      if (CODEC == 1) {
+        dxt5_alpha_planes(w[0], tlo, thi);
+        lo24 = w[0] >> 16 | (w[1] & 0xffu) << 16;  // codes of pixels 0-7 / 8-15
+        hi24 = w[1] >> 8;
+      }
+      ICAMD_UNROLL
+      for (int qy = 0; qy < 2; ++qy) {
+        const uint32_t t = perm(0u, bits, qy ? 0x0c030c02u : 0x0c010c00u);  // index bytes of rows (2 qy, 2 qy + 1)
+        uint32_t q0 = dxt_quad_average(P, dxt_quad_selector<0>(t));
+        uint32_t q1 = dxt_quad_average(P, dxt_quad_selector<1>(t));
+        if (CODEC == 1) {
+          const uint32_t h = qy ? hi24 : lo24;
+          const uint32_t a0 = udot4(perm(thi, tlo, dxt5_quad_alpha_selector<0>(h)), 0x40404040u, 0u);
+          const uint32_t a1 = udot4(perm(thi, tlo, dxt5_quad_alpha_selector<1>(h)), 0x40404040u, 0u);
+          q0 |= (a0 & 0xff00u) << 16;
+          q1 |= (a1 & 0xff00u) << 16;
+        }
+        // StoreDownsampledPixels4x4 (pixel4x4.h:152-162): block (i, j) fills the 2x2 quadrant at (2 i, 2 j)
+        px[4 * (2 * i + qy) + 2 * j] = q0;
+        px[4 * (2 * i + qy) + 2 * j + 1] = q1;
+      }
+    }
+  }
+}
+
+// ---- the same for ETC1 (r04).  A sub-block has four colours -- base + {a, b, -a, -b}, each channel clamped to 0..255
+// (etc.cc:101-125) -- so an ETC1 block is two four-entry palettes; a 2x2 pixel quad never straddles the two sub-blocks
+// (they split the block at column 2 or at row 2), so one palette serves a whole quad.
+//
+// P[s][ch]: byte k of = channel ch of sub-block s's candidate k (k = modifier index: +a, +b, -a, -b).  Returns flip.
+ICAMD_DEV bool etc1_palette_planes(uint32_t w0, uint32_t P[2][3]) {
+  const uint32_t hi = perm(0u, w0, 0x00010203u);  // big-endian word (etc.cc:172-180)
+  const bool diff = (hi & 2u) != 0u;
+  const uint32_t cws[2] = { (hi >> 5) & 7u, (hi >> 2) & 7u };
+  ICAMD_UNROLL
+  for (int sb = 0; sb < 2; ++sb) {
+    const uint32_t cw = cws[sb], sh = (cw & 3u) * 8u;
+    const uint32_t a = bfe(cw < 4u ? kEtcModA_lo : kEtcModA_hi, sh, 8), b = bfe(cw < 4u ? kEtcModB_lo : kEtcModB_hi, sh, 8);
+    const uint32_t ab = a << 8 | b << 24;  // the two magnitudes in the high bytes of the 16-bit lanes
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      // base colour of this sub-block exactly as decode_etc1 / the reference's decoder reconstruct it (etc.cc:198-273):
+      // plain int arithmetic, so a differential base whose 5-bit sum leaves 0..31 is negative or above 255 here and only
+      // the final base + modifier is clamped
+      int32_t sbase;
+      if (diff) {
+        const int32_t b5 = (int32_t)((hi >> (27 - 8 * ch)) & 31u), d3 = (int32_t)((hi >> (24 - 8 * ch)) & 7u);
+        const int32_t v5 = sb == 0 ? b5 : b5 + (d3 >= 4 ? d3 - 8 : d3);  // ExtendSignBit, bit_util.h:61-69
+        sbase = (v5 << 3) | ((v5 >> 2) & 7);                              // Extend5Bit, color_util.h:200-202
+      } else {
+        sbase = (int32_t)(((hi >> ((sb == 0 ? 28 : 24) - 8 * ch)) & 15u) * 17u);
+      }
+      // candidates clamp(sbase +/- m): with the value in the high byte of a 16-bit lane, saturating adds / subtracts clamp
+      // at 255 / 0 by themselves for sbase in 0..255; the (rare) out-of-range bases take the plain-integer form
+      const uint32_t b2 = ((uint32_t)sbase & 0xffu) * 0x01000100u;
+      uint32_t up = pk_addsat_u16(b2, ab), dn = pk_subsat_u16(b2, ab);
+      uint32_t plane = perm(dn, up, 0x07050301u);
+      if (!wave_all(sbase >= 0 && sbase <= 255)) {
+        const uint32_t k0 = clamp255(sbase + (int32_t)a), k1 = clamp255(sbase + (int32_t)b);
+        const uint32_t k2 = clamp255(sbase - (int32_t)a), k3 = clamp255(sbase - (int32_t)b);
+        const uint32_t slow = k0 | k1 << 8 | k2 << 16 | k3 << 24;
+        plane = (sbase >= 0 && sbase <= 255) ? plane : slow;
+      }
+      P[sb][ch] = plane;
+    }
+  }
+  return (hi & 1u) != 0u;
+}
+
+// Selector of the quad at columns (2 QX, 2 QX + 1), rows (2 QY, 2 QY + 1): byte i = modifier index of one of the quad's
+// pixels (the ORDER inside the quad does not matter for a sum).  lo = the block's big-endian index word: bit 4x + y holds
+// the LSB of pixel (x, y)'s index, bit 16 + 4x + y the MSB (etc.cc:131-156).
+template <int QX, int QY>
+ICAMD_DEV uint32_t etc1_quad_selector(uint32_t lo) {
+  const uint32_t z = (8 * QX + 2 * QY) ? lo >> (8 * QX + 2 * QY) : lo;  // the quad's bits now sit at 0, 1, 4, 5 (+ 16)
+  // bits 0, 1, 4, 5 -> bit 0 of bytes 0..3: one multiply (the partial products that collide carry no further than bit 14)
+  const uint32_t l = umad24(z & 0x33u, 0x81081u, 0u) & 0x01010101u;
+  const uint32_t m = umad24(bfe(z, 16, 6) & 0x33u, 0x81081u, 0u) & 0x01010101u;
+  return l | m << 1;
+}
+
+// px[16] <- 2x2 averages of the 8x8 pixels of four ETC1 blocks s[i][j] (2 dwords each); see dxt_downsample_2x2.
+ICAMD_DEV void etc1_downsample_2x2(const uint32_t *const s[2][2], uint32_t px[16]) {
+  ICAMD_UNROLL
+  for (int i = 0; i < 2; ++i) {
+    ICAMD_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      uint32_t P[2][3];
+      const bool flip = etc1_palette_planes(s[i][j][0], P);
+      const uint32_t lo = perm(0u, s[i][j][1], 0x00010203u);
+      // sub-block of quad (qx, qy): flip ? qy : qx
+      uint32_t Pm[2][3];  // palettes of the quads (1, 0) and (0, 1)
+      ICAMD_UNROLL
+      for (int ch = 0; ch < 3; ++ch) {
+        Pm[0][ch] = flip ? P[0][ch] : P[1][ch];  // (qx, qy) = (1, 0)
+        Pm[1][ch] = flip ? P[1][ch] : P[0][ch];  // (0, 1)
+      }
+      px[4 * (2 * i) + 2 * j] = dxt_quad_average(P[0], etc1_quad_selector<0, 0>(lo));
+      px[4 * (2 * i) + 2 * j + 1] = dxt_quad_average(Pm[0], etc1_quad_selector<1, 0>(lo));
+      px[4 * (2 * i + 1) + 2 * j] = dxt_quad_average(Pm[1], etc1_quad_selector<0, 1>(lo));
+      px[4 * (2 * i + 1) + 2 * j + 1] = dxt_quad_average(P[1], etc1_quad_selector<1, 1>(lo));
+    }
+  }
+}
+
 // Decode any block (DXT1 / DXT5 / ETC1, codec ids of ic_amd.h) to packed pixels, no red/blue swap
 // (Downsample and the transcoder always pass swap = false).
 template <int CODEC>

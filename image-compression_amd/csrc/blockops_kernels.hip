@@ -10,7 +10,7 @@ namespace {
 constexpr int kWords(int codec) { return codec == ICAMD_DXT5 ? 4 : 2; }
 }
 
-template <int CODEC>
+template <int CODEC, int STRATEGY>
 __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
   constexpr int W = kWords(CODEC);
   const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
@@ -29,7 +29,7 @@ __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
   }
   const int kind = in_rows ? kPadColumn : (in_cols ? kPadRow : kPadCorner);  // helper.h:427-470
   if (CODEC == ICAMD_ETC1) {
-    const Out8 o = etc1_pad_block(w[0], w[1], kind, P.etc_strategy);
+    const Out8 o = etc1_pad_block(w[0], w[1], kind, (uint32_t)STRATEGY);  // compile-time strategy: see downsample_one
     dst[0] = o.lo; dst[1] = o.hi;
   } else if (CODEC == ICAMD_DXT1) {
     dst[0] = w[0];
@@ -44,20 +44,46 @@ __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
   }
 }
 
-template <int CODEC>
+// STRATEGY: the ETC1 re-encode strategy as a compile-time constant (one kernel per strategy, like the encoders: the
+// kSmallerError search is not carried along by a kHeuristic downsample and vice versa); ignored for DXT.
+template <int CODEC, int STRATEGY>
 __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t k, BlockStash &stash) {
   constexpr int W = kWords(CODEC);
-  const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src);
+  // image of a batched launch, then (r, c) inside its output grid
+  uint32_t img = 0, kk = k;
+  if (P.n_images > 1) {
+    img = fastdiv(k, P.div_out_per_image);
+    kk = k - img * P.out_per_image;
+  }
+  const uint32_t r = fastdiv(kk, P.div_out_cols), c = kk - r * P.out_cols;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src + (size_t)img * P.src_image_stride);
   uint32_t px[16], tmp[16];
   if (P.in_rows > 1 && P.in_cols > 1) {  // DownsampleBlocks2x2
+    if (CODEC != ICAMD_ETC1) {
+      // the two blocks of a source row are adjacent in memory: one 16-byte (DXT1) / two 16-byte (DXT5) loads per row
+      uint32_t w[2][2][W];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t *q = src + ((size_t)(2 * r + i) * P.in_cols + 2 * c) * W;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        decode_any<CODEC>(src + ((size_t)(2 * r + i) * P.in_cols + 2 * c + j) * W, tmp);
-        store_downsampled(tmp, 2 * i, 2 * j, px);
+        for (int h = 0; h < 2 * W / 4; ++h) {
+          const U4 v = *reinterpret_cast<const U4 *>(q + 4 * h);
+          uint32_t *d = &w[0][0][0] + (i * 2 * W + 4 * h);
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
       }
+      const uint32_t *const s4[2][2] = { { w[0][0], w[0][1] }, { w[1][0], w[1][1] } };
+      dxt_downsample_2x2<CODEC>(s4, px);
+    } else {
+      uint32_t w[2][2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const U4 v = *reinterpret_cast<const U4 *>(src + ((size_t)(2 * r + i) * P.in_cols + 2 * c) * 2);
+        w[i][0][0] = v.x; w[i][0][1] = v.y; w[i][1][0] = v.z; w[i][1][1] = v.w;
+      }
+      const uint32_t *const s4[2][2] = { { w[0][0], w[0][1] }, { w[1][0], w[1][1] } };
+      etc1_downsample_2x2(s4, px);
+    }
   } else if (P.in_rows > 1) {  // DownsampleBlocks2x1: one block column
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -94,29 +120,39 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
       for (int j = 0; j < 2; ++j) store_downsampled(tmp, 2 * i, 2 * j, px);
   }
   uint32_t out[4];
-  encode_any<CODEC>(px, P.etc_strategy, stash, out);
-  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + (size_t)k * W;
-#pragma unroll
-  for (int i = 0; i < W; ++i) dst[i] = out[i];
+  encode_any<CODEC>(px, CODEC == ICAMD_ETC1 ? (uint32_t)STRATEGY : 0u, stash, out);
+  uint8_t *dst = P.dst + (size_t)img * P.dst_image_stride + (size_t)kk * (W * 4);
+  if (W == 4) store_stream16(dst, out[0], out[1], out[2], out[3]);
+  else store_stream8(dst, out[0], out[1]);
 }
 
-#define ICAMD_BLOCKOP_KERNELS(NAME, CODEC)                                                                     \
+#define ICAMD_PAD_KERNEL(NAME, CODEC, STRATEGY)                                                                \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pad_##NAME##_kernel(BlockOpParams P) { \
     const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
-    if (k < P.total_out) pad_one<CODEC>(P, k);                                                                 \
-  }                                                                                                            \
+    if (k < P.total_out) pad_one<CODEC, STRATEGY>(P, k);                                                       \
+  }
+#define ICAMD_DOWNSAMPLE_KERNEL(NAME, CODEC, STRATEGY)                                                         \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup)                                           \
   icamd_downsample_##NAME##_kernel(BlockOpParams P) {                                                          \
     __shared__ uint32_t lds_px[4][kThreadsPerWorkgroup][4];                                                    \
     BlockStash stash;                                                                                          \
     stash.base = &lds_px[0][threadIdx.x][0];                                                                   \
     const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
-    if (k < P.total_out) downsample_one<CODEC>(P, k, stash);                                                   \
+    if (k < P.total_out) downsample_one<CODEC, STRATEGY>(P, k, stash);                                         \
   }
 
-ICAMD_BLOCKOP_KERNELS(dxt1, ICAMD_DXT1)
-ICAMD_BLOCKOP_KERNELS(dxt5, ICAMD_DXT5)
-ICAMD_BLOCKOP_KERNELS(etc1, ICAMD_ETC1)
+ICAMD_PAD_KERNEL(dxt1, ICAMD_DXT1, 0)
+ICAMD_PAD_KERNEL(dxt5, ICAMD_DXT5, 0)
+ICAMD_PAD_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
+ICAMD_PAD_KERNEL(etc1_split_v, ICAMD_ETC1, 1)
+ICAMD_PAD_KERNEL(etc1, ICAMD_ETC1, 2)
+ICAMD_PAD_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
+ICAMD_DOWNSAMPLE_KERNEL(dxt1, ICAMD_DXT1, 0)
+ICAMD_DOWNSAMPLE_KERNEL(dxt5, ICAMD_DXT5, 0)
+ICAMD_DOWNSAMPLE_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
+ICAMD_DOWNSAMPLE_KERNEL(etc1_split_v, ICAMD_ETC1, 1)
+ICAMD_DOWNSAMPLE_KERNEL(etc1, ICAMD_ETC1, 2)  // kSmallerError (and every value the reference's default: label maps to it)
+ICAMD_DOWNSAMPLE_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
 
 extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_to_etc1_kernel(uint2 *blocks, uint32_t n) {
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
@@ -133,8 +169,12 @@ hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
   const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_pad_dxt1_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_pad_dxt5_kernel, grid, block, 0, stream, P);
-  else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_pad_etc1_kernel, grid, block, 0, stream, P);
-  else return hipErrorInvalidValue;
+  else if (codec == ICAMD_ETC1) {
+    if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_split_h_kernel, grid, block, 0, stream, P);
+    else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_pad_etc1_split_v_kernel, grid, block, 0, stream, P);
+    else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_pad_etc1_heuristic_kernel, grid, block, 0, stream, P);
+    else hipLaunchKernelGGL(icamd_pad_etc1_kernel, grid, block, 0, stream, P);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -143,8 +183,12 @@ hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stre
   const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_downsample_dxt1_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_downsample_dxt5_kernel, grid, block, 0, stream, P);
-  else if (codec == ICAMD_ETC1) hipLaunchKernelGGL(icamd_downsample_etc1_kernel, grid, block, 0, stream, P);
-  else return hipErrorInvalidValue;
+  else if (codec == ICAMD_ETC1) {
+    if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_downsample_etc1_split_h_kernel, grid, block, 0, stream, P);
+    else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_downsample_etc1_split_v_kernel, grid, block, 0, stream, P);
+    else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_downsample_etc1_heuristic_kernel, grid, block, 0, stream, P);
+    else hipLaunchKernelGGL(icamd_downsample_etc1_kernel, grid, block, 0, stream, P);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -666,12 +666,14 @@ int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, 
   return ICAMD_OK;
 }
 
-int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw,
-                            const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) {
+int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, uint32_t n_images,
+                                  const void *d_blocks, size_t src_image_stride_bytes, void *d_out,
+                                  size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
   int codec;
   if (!d_blocks || !d_out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
-  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
-    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
+  if (n_images == 0) return ICAMD_OK;
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
   icamd::BlockOpParams P;
   P.in_rows = num_blocks4(uh); P.in_cols = num_blocks4(uw);
   // helper.h:281-284, :340-341
@@ -679,19 +681,36 @@ int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32
   if (P.in_rows == 1 && P.in_cols == 1 && (uh == 3 || uw == 3)) return ICAMD_FALSE;
   const uint32_t dh = (uh + 1) / 2, dw = (uw + 1) / 2;
   P.out_rows = num_blocks4(dh); P.out_cols = num_blocks4(dw);
-  if (out_size != icamd_encoded_size(codec, dh, dw)) return ICAMD_FALSE;
+  if (out_size_per_image != icamd_encoded_size(codec, dh, dw)) return ICAMD_FALSE;
+  if (n_images > 1 && (src_image_stride_bytes < icamd_encoded_size(codec, uh, uw) || dst_image_stride_bytes < out_size_per_image))
+    return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  P.src = static_cast<const uint8_t *>(d_blocks);
-  P.dst = static_cast<uint8_t *>(d_out);
-  const uint64_t total = (uint64_t)P.out_rows * P.out_cols;
-  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
-  P.total_out = (uint32_t)total;
+  const uint64_t per = (uint64_t)P.out_rows * P.out_cols;
+  if (per >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one image");
   P.etc_strategy = (uint32_t)etc_strategy;
   P.src_height = uh; P.src_width = uw;
   P.div_out_cols = icamd::make_fastdiv(P.out_cols);
-  ICAMD_HIP(icamd::launch_downsample(codec, P, static_cast<hipStream_t>(hip_stream)), "launch downsample");
+  P.out_per_image = (uint32_t)per;
+  P.div_out_per_image = icamd::make_fastdiv(P.out_per_image);
+  P.src_image_stride = src_image_stride_bytes;
+  P.dst_image_stride = dst_image_stride_bytes;
+  // as many images per launch as the 32-bit block index allows
+  const uint64_t group = std::max<uint64_t>(1, ((1ull << 31) - 1) / per);
+  for (uint64_t first = 0; first < n_images; first += group) {
+    const uint64_t count = std::min<uint64_t>(group, n_images - first);
+    P.src = static_cast<const uint8_t *>(d_blocks) + first * src_image_stride_bytes;
+    P.dst = static_cast<uint8_t *>(d_out) + first * dst_image_stride_bytes;
+    P.n_images = (uint32_t)count;
+    P.total_out = (uint32_t)(per * count);
+    ICAMD_HIP(icamd::launch_downsample(codec, P, static_cast<hipStream_t>(hip_stream)), "launch downsample");
+  }
   return ICAMD_OK;
+}
+
+int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw,
+                            const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) {
+  return icamd_downsample_batch_device(compressor, etc_strategy, format, uh, uw, 1, d_blocks, 0, d_out, 0, out_size, hip_stream);
 }
 
 int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream) {

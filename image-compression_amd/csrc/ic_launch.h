@@ -99,6 +99,10 @@ struct BlockOpParams {
   uint32_t etc_strategy;
   uint32_t src_height, src_width;  // uncompressed pixels of the source (Downsample's single-block case)
   FastDiv div_out_cols;
+  // Downsample only: n_images equally shaped block grids per launch (total_out = out_rows * out_cols * n_images)
+  uint32_t n_images = 1, out_per_image = 0;
+  uint64_t src_image_stride = 0, dst_image_stride = 0;  // bytes
+  FastDiv div_out_per_image = { 0, 0, 1 };
 };
 hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream);
 hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream);

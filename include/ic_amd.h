@@ -183,6 +183,13 @@ int icamd_pad(int compressor, int etc_strategy, int format, uint32_t compressed_
 int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
                             uint32_t uncompressed_width, const void *d_blocks, void *d_out, size_t out_size,
                             void *hip_stream);
+/* Extension: the same on n_images equally shaped block grids in ONE launch (image i at d_blocks + i * src_image_stride_bytes ->
+ * d_out + i * dst_image_stride_bytes; strides multiples of 4).  One 4096^2 DXT1 level is 10 MB of traffic -- less than the
+ * fixed cost of a launch is worth -- so a mip generator that halves many textures feeds them as a batch. */
+int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
+                                  uint32_t uncompressed_width, uint32_t n_images, const void *d_blocks,
+                                  size_t src_image_stride_bytes, void *d_out, size_t dst_image_stride_bytes,
+                                  size_t out_size_per_image, void *hip_stream);
 int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uncompressed_height,
                      uint32_t uncompressed_width, const uint8_t *blocks, uint8_t *out, size_t out_size);
 

@@ -48,8 +48,17 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
                                            ctypes.c_void_p(dn[i].data_ptr()), dn.shape[1], sh)
             assert rc == 0
     t = timeit(down, 5)
-    print("downsample %-5s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images)" % (
+    print("downsample %-5s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)" % (
         name, px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
+    # the same as ONE batched launch (icamd_downsample_batch_device, r04), per ETC1 re-encode strategy
+    for strat in ((2, 3) if codec == 2 else (2,)):
+        def down_b():
+            rc = L.icamd_downsample_batch_device(compressor, strat, fmt, n, n, batch, ctypes.c_void_p(blocks.data_ptr()), per_in,
+                                                 ctypes.c_void_p(dn.data_ptr()), dn.shape[1], dn.shape[1], sh)
+            assert rc == 0
+        t = timeit(down_b, 10)
+        print("downsample %-5s batched%s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one launch)" % (
+            name, " strategy %d" % strat if codec == 2 else "", px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
     if codec == 0:
         work = blocks.clone()
         def tr():

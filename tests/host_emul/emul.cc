@@ -137,6 +137,17 @@ static int emul_downsample_t(int strategy, uint32_t uh, uint32_t uw, const uint8
           decode_any<CODEC>(src + ((size_t)(2 * r + i) * ocols + 2 * c + j) * W, tmp);
           store_downsampled(tmp, 2 * i, 2 * j, px);
         }
+        {  // what the kernel runs for 2x2 grids (palette planes + quad selectors) must give the same pixels
+          const uint32_t *const s4[2][2] = {
+              { src + ((size_t)(2 * r) * ocols + 2 * c) * W, src + ((size_t)(2 * r) * ocols + 2 * c + 1) * W },
+              { src + ((size_t)(2 * r + 1) * ocols + 2 * c) * W, src + ((size_t)(2 * r + 1) * ocols + 2 * c + 1) * W } };
+          uint32_t fast[16];
+          if (CODEC == 2) etc1_downsample_2x2(s4, fast);
+          else dxt_downsample_2x2<CODEC == 1 ? 1 : 0>(s4, fast);
+          for (int i = 0; i < 16; ++i)
+            if ((fast[i] ^ px[i]) & (CODEC == 1 ? 0xffffffffu : 0x00ffffffu)) return 0;
+          memcpy(px, fast, sizeof(px));
+        }
       } else if (orows > 1) {
         for (int i = 0; i < 2; ++i) { decode_any<CODEC>(src + (size_t)(2 * r + i) * W, tmp); store_downsampled(tmp, 2 * i, 0, px); store_downsampled(tmp, 2 * i, 2, px); }
       } else if (ocols > 1) {

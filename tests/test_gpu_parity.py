@@ -1086,3 +1086,44 @@ print("WORK DONE")
     assert "WORK DONE" in p.stdout
     bad = [l for l in p.stderr.splitlines() if "hipError" in l or "HIP error" in l or "Assertion" in l or "core dumped" in l]
     assert not bad, bad[:10]
+
+
+def test_downsample_batch_and_arbitrary_block_words(pkg):
+    """icamd_downsample_batch_device (r04 extension): n equally shaped grids in one launch == n single calls == the oracle;
+    and the DXT fast path (palette planes + quad selectors) on arbitrary block words -- three-colour DXT1 blocks, equal
+    endpoints, DXT5's six-value alpha -- against the oracle's decode-average-encode."""
+    import torch
+    g = np.random.Generator(np.random.PCG64(23))
+    for compressor, fmt, codec, strategy in ((T.DXTC, T.RGB, T.DXT1, 2), (T.DXTC, T.RGBA, T.DXT5, 2), (T.ETC, T.RGB, T.ETC1, 3),
+                                            (T.ETC, T.RGB, T.ETC1, 2), (T.ETC, T.RGB, T.ETC1, 1)):
+        bb = 16 if codec == T.DXT5 else 8
+        h, w, n = 64, 96, 5
+        raw = g.integers(0, 256, size=(n, (h // 4) * (w // 4), bb), dtype=np.uint8)
+        if codec != T.ETC1:
+            col = raw[1, :, bb - 8:]
+            col[:, :4] = np.sort(col[:, :4].copy().view(np.uint16), axis=1).view(np.uint8)  # c0 <= c1
+            raw[2, :, bb - 6:bb - 4] = raw[2, :, bb - 8:bb - 6]                               # c0 == c1
+            if codec == T.DXT5:
+                raw[3, :, :2] = np.sort(raw[3, :, :2], axis=1)                                # alpha0 <= alpha1
+        else:
+            raw[:] = np.stack([np.frombuffer(T.oracle_compress(T.ETC, T.RGB, T.s_mixed(h, w, 3, index=70 + i), h, w), np.uint8)
+                               .reshape(-1, 8) for i in range(n)])
+        want = [T.oracle_downsample(compressor, fmt, raw[i].tobytes(), h, w, strategy) for i in range(n)]
+        got = pkg.downsample_device(compressor, fmt, _dev(raw.reshape(n, -1)), h, w, etc_strategy=strategy, n_images=n)
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert got[i].cpu().numpy().tobytes() == want[i], (codec, strategy, i)
+            assert pkg.downsample_host(compressor, fmt, raw[i].tobytes(), h, w, strategy) == want[i]
+    # a batch with padded strides, and a refused geometry
+    raw = g.integers(0, 256, size=(3, 16 * 16 * 8 + 24), dtype=np.uint8)
+    d = _dev(raw)
+    out = torch.zeros((3, 8 * 8 * 8 + 16), dtype=torch.uint8, device="cuda")
+    rc = pkg.lib().icamd_downsample_batch_device(T.DXTC, 2, T.RGB, 64, 64, 3, pkg.ctypes.c_void_p(d.data_ptr()), raw.shape[1],
+                                                 pkg.ctypes.c_void_p(out.data_ptr()), out.shape[1], 8 * 8 * 8, None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    for i in range(3):
+        assert out[i, :512].cpu().numpy().tobytes() == T.oracle_downsample(T.DXTC, T.RGB, raw[i, :2048].tobytes(), 64, 64, 2)
+        assert not out[i, 512:].any()
+    assert pkg.lib().icamd_downsample_batch_device(T.DXTC, 2, T.RGB, 12, 64, 3, pkg.ctypes.c_void_p(d.data_ptr()), raw.shape[1],
+                                                   pkg.ctypes.c_void_p(out.data_ptr()), out.shape[1], 8 * 2 * 8, None) == 1  # 3 block rows

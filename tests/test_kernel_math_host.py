@@ -179,6 +179,30 @@ def test_blockops_math_matches_oracle(emul):
             out = np.zeros(max(len(want) if want else 0, bb), np.uint8)
             ok = emul.emul_downsample(codec, strategy, h, w, b.ctypes.data, out.ctypes.data)
             assert (out[:len(want)].tobytes() if ok else None) == want, (codec, h, w)
+    # Downsample of ARBITRARY block words (not encoder output): DXT1 three-colour mode and equal endpoints, DXT5 six-value
+    # alpha -- the kernel's palette-plane / quad-selector form (dxt_downsample_2x2) against the oracle's decode-average-encode
+    g = np.random.Generator(np.random.PCG64(17))
+    for compressor, fmt, codec in [(T.DXTC, T.RGB, T.DXT1), (T.DXTC, T.RGBA, T.DXT5), (T.ETC, T.RGB, T.ETC1)]:
+        bb = 16 if codec == T.DXT5 else 8
+        for trial in range(6):  # (ETC1: random words = half differential, many with a base outside 0..31)
+            h, w = 32, 64
+            raw = g.integers(0, 256, size=(h // 4) * (w // 4) * bb, dtype=np.uint8).reshape(-1, bb)
+            col = raw[:, bb - 8:]
+            if trial == 1:   # c0 < c1 everywhere (DXT1: three colours + black)
+                c = np.sort(col[:, :4].copy().view(np.uint16), axis=1)
+                col[:, :4] = c.view(np.uint8)
+            elif trial == 2:  # c0 == c1
+                col[:, 2:4] = col[:, 0:2]
+            elif trial == 3 and codec == T.DXT5:  # alpha0 <= alpha1: the six-value mode
+                a = np.sort(raw[:, :2], axis=1)
+                raw[:, :2] = a
+            blocks = raw.tobytes()
+            strategy = 3 if codec == T.ETC1 else 2
+            want = T.oracle_downsample(compressor, fmt, blocks, h, w, strategy)
+            out = np.zeros(len(want), np.uint8)
+            b = np.frombuffer(blocks, np.uint8)
+            assert emul.emul_downsample(codec, strategy, h, w, b.ctypes.data, out.ctypes.data), (codec, trial)
+            assert out.tobytes() == want, (codec, trial)
     g = np.random.Generator(np.random.PCG64(3))
     raw = g.integers(0, 256, size=8 * 2048, dtype=np.uint8)
     want = T.oracle_transcode(raw.tobytes())
