@@ -18,35 +18,128 @@ namespace icamd {
 // code of kSmallerError (two partitions x two sub-blocks x eight codewords, unrolled) does not carry the single-partition
 // and heuristic paths along -- the kernel is bound by instruction issue AND sensitive to its code footprint
 // (profiles/r03_ab_etc1_*.log).  The default: label of etc_compressor.cc:575-584 makes every other value kSmallerError.
+// The part of etc1_encode_one after the block is in registers: the per-wave choice of instantiation.  constant / busy are
+// per-lane properties of the block (one colour; sums r + g + b spread by ICAMD_ETC1_BUSY_SPREAD or more).
+template <int STRATEGY>
+__device__ __forceinline__ Out8 etc1_encode_classified(const uint32_t px[16], bool constant, bool busy) {
+  Out8 c;
+  // One-colour blocks are encoded by a form of their own (one pixel against the 32 candidates).  A wave of nothing else
+  // skips the searches altogether; inside a mixed wave those lanes neither vote in the searches' wave-uniform
+  // decisions nor count for the content probe, and their results are replaced afterwards.
+  if (wave_all(!constant)) {  // (the common case: exactly the code of a build without the one-colour forms)
+    if (wave_count(busy) >= 48u) c = encode_etc1_block<true, false>(px, (uint32_t)STRATEGY);  // busy wave: mixed tier, no pruning
+    else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true>(px, (uint32_t)STRATEGY);           // calm wave: pruning (+ tier?)
+  } else if (wave_all(constant)) {
+    c = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
+  } else {
+    if (4u * wave_count(!constant && busy) >= 3u * wave_count(!constant))
+      c = encode_etc1_block<true, false, true>(px, (uint32_t)STRATEGY, constant);
+    else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true, true>(px, (uint32_t)STRATEGY, constant);
+    const Out8 cc = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
+    c.lo = constant ? cc.lo : c.lo;
+    c.hi = constant ? cc.hi : c.hi;
+  }
+  return c;
+}
+
+// STRATEGY is a compile-time constant: one kernel per EtcCompressor::CompressionStrategy, so that the straight-line
+// code of kSmallerError (two partitions x two sub-blocks x eight codewords, unrolled) does not carry the single-partition
+// and heuristic paths along -- the kernel is bound by instruction issue AND sensitive to its code footprint
+// (profiles/r03_ab_etc1_*.log).  The default: label of etc_compressor.cc:575-584 makes every other value kSmallerError.
+//
+// REGROUP (r04, the searching strategies): a one-colour block is encoded by a form that costs a tenth of the searches, but
+// only a wave of 64 such blocks skips the searches -- one noisy tile among flat ones (UI, atlases, map tiles) makes its
+// 63 neighbours wait.  A workgroup (256 blocks) that holds BOTH kinds therefore partitions itself first: per-wave ballots
+// give the counts and the rank inside the kind, the 16 pixel dwords travel through LDS to the lane of their rank -- one-colour
+// blocks first, the rank rotated by the workgroup's index so that the searching waves of neighbouring workgroups land on
+// different SIMDs -- and each lane stores its result straight to the block it now holds.  Workgroups of one kind (all of
+// noise / photographic content) pay two ballots, one barrier and a few adds, nothing else.
+// (r04 also measured the full version of VERDICT r03 item 2 -- a counting sort of all 256 blocks by (one colour | calm |
+//  busy) x room-to-0/255 class, results returned through LDS: noise 248.7 -> 233.6, smooth 182.4 -> 174.6, flat 338.7 ->
+//  328.6 Gpix/s, i.e. slower everywhere.  scripts/etc1_search_sim.py shows why: a block's four searches have four different
+//  rooms (two partitions x two sub-blocks), so one per-block key homogenises none of them on noise, smooth gradients are
+//  homogeneous per wave already, and a returning barrier parks the finished one-colour waves behind the searching one.)
+// NOT SHIPPED (default 0): three versions measured, none faster on any content -- profiles/r04_ab_etc1_regroup.log (v3, this
+// code: noise 249.3 -> 241.6, smooth 180.9 -> 178.3, flat 332.9 -> 336.9 Gpix/s).  Kept behind the macro for A/B runs.
+#ifndef ICAMD_ETC1_REGROUP
+#define ICAMD_ETC1_REGROUP 0
+#endif
+
 template <int COMPS, int STRATEGY>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
   const TileCoord t = locate_tile<false>(P);
-  if (!t.valid) return;
-  uint32_t px[16];
-  load_tile_block<COMPS>(P, t, px);
-  Out8 c;
-  if (STRATEGY == 3) {
-    c = encode_etc1_block<false>(px, 3u);
-  } else {
-    // One-colour blocks are encoded by a form of their own (one pixel against the 32 candidates).  A wave of nothing else
-    // skips the searches altogether; inside a mixed wave those lanes neither vote in the searches' wave-uniform
-    // decisions nor count for the content probe, and their results are replaced afterwards.
-    const uint32_t spread = etc1_block_spread(px);
-    const bool constant = etc1_constant_block(px, spread);
-    if (wave_all(!constant)) {  // (the common case: exactly the code of a build without the one-colour forms)
-      if (etc1_busy_wave(spread)) c = encode_etc1_block<true, false>(px, (uint32_t)STRATEGY);  // busy wave: mixed tier, no pruning
-      else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true>(px, (uint32_t)STRATEGY);          // calm wave: pruning (+ tier?)
-    } else if (wave_all(constant)) {
-      c = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
+  if (STRATEGY == 3 || !ICAMD_ETC1_REGROUP) {
+    if (!t.valid) return;
+    uint32_t px[16];
+    load_tile_block<COMPS>(P, t, px);
+    Out8 c;
+    if (STRATEGY == 3) {
+      c = encode_etc1_block<false>(px, 3u);
     } else {
-      if (etc1_busy_wave(spread, constant)) c = encode_etc1_block<true, false, true>(px, (uint32_t)STRATEGY, constant);
-      else c = encode_etc1_block<ICAMD_ETC1_CALM_TIER, true, true>(px, (uint32_t)STRATEGY, constant);
-      const Out8 cc = encode_etc1_constant_block(px[0], (uint32_t)STRATEGY);
-      c.lo = constant ? cc.lo : c.lo;
-      c.hi = constant ? cc.hi : c.hi;
+      const uint32_t spread = etc1_block_spread(px);
+      c = etc1_encode_classified<STRATEGY>(px, etc1_constant_block(px, spread), spread >= ICAMD_ETC1_BUSY_SPREAD);
     }
+    store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
+    return;
   }
-  store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
+  __shared__ uint32_t lds_px[17][kThreadsPerWorkgroup];  // [pixel 0..15, (busy | destination offset)][rank]
+  __shared__ uint32_t lds_cnt[2][4];                      // per wave: one-colour blocks, searching blocks
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  uint32_t px[16];
+  uint32_t kind = 2u;  // lanes without a block (partial tiles at the image's edges)
+  bool busy = false;
+  if (t.valid) {
+    load_tile_block<COMPS>(P, t, px);
+    const uint32_t spread = etc1_block_spread(px);
+    busy = spread >= ICAMD_ETC1_BUSY_SPREAD;
+    kind = etc1_constant_block(px, spread) ? 0u : 1u;
+  }
+  // counts per wave by ballot (no atomics: 64 lanes on one LDS counter serialise), one LDS word per wave and kind
+  const uint64_t m_const = __ballot(kind == 0u), m_search = __ballot(kind == 1u);
+  if ((tid & 63u) == 0u) {
+    lds_cnt[0][wave] = (uint32_t)__popcll(m_const);
+    lds_cnt[1][wave] = (uint32_t)__popcll(m_search);
+  }
+  __syncthreads();
+  uint32_t n_const = 0, n_search = 0, before_const = 0, before_search = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4u; ++w) {
+    const uint32_t c = lds_cnt[0][w], q = lds_cnt[1][w];
+    before_const += w < wave ? c : 0u;
+    before_search += w < wave ? q : 0u;
+    n_const += c;
+    n_search += q;
+  }
+  uint8_t *const dst_base = P.dst + (uint64_t)t.img * P.dst_image_stride + ((uint64_t)t.brow0 * P.block_cols + t.bcol0) * 8u;
+  const uint32_t dst_off = (t.ly * P.block_cols + t.lx) * 8u;
+  if (n_const == 0u || n_search == 0u) {  // one kind only (workgroup-uniform): nothing to regroup
+    if (kind == 2u) return;
+    const Out8 c = etc1_encode_classified<STRATEGY>(px, kind == 0u, busy);
+    store_stream8(dst_base + dst_off, c.lo, c.hi);
+    return;
+  }
+  // rank: one-colour blocks, then searching blocks, then the lanes without a block; rotated by a hash of the workgroup's
+  // index -- a CU receives workgroups whose indices differ by a multiple of the CU count, so anything periodic in
+  // blockIdx would put the searching wave of every resident workgroup on the same SIMD
+  const uint32_t lane_lt = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_const >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_const, 0u));
+  const uint32_t lane_lt_s = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_search >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_search, 0u));
+  const uint32_t wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const uint32_t rot = ((wg * 0x9e3779b1u) >> 30) * 64u;
+  const uint32_t tail = n_const + n_search;  // (lanes without a block: any distinct slots past the blocks)
+  const uint32_t plain = kind == 0u ? before_const + lane_lt : kind == 1u ? n_const + before_search + lane_lt_s
+                                    : tail + (tid - (before_const + lane_lt + before_search + lane_lt_s));
+  const uint32_t rank = (plain + rot) & 255u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds_px[i][rank] = kind == 2u ? 0u : px[i];
+  // destination offsets are multiples of 8: bit 0 carries `busy`, bit 1 `one colour`, bit 2 `no block`
+  lds_px[16][rank] = dst_off | (busy ? 1u : 0u) | (kind == 0u ? 2u : 0u) | (kind == 2u ? 4u : 0u);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) px[i] = lds_px[i][tid];
+  const uint32_t tag = lds_px[16][tid];
+  if (tag & 4u) return;
+  const Out8 c = etc1_encode_classified<STRATEGY>(px, (tag & 2u) != 0u, (tag & 1u) != 0u);
+  store_stream8(dst_base + (tag & ~7u), c.lo, c.hi);
 }
 
 extern "C" {
