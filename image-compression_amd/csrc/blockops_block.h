@@ -276,6 +276,141 @@ ICAMD_DEV void etc1_downsample_2x2(const uint32_t *const s[2][2], uint32_t px[16
   }
 }
 
+// ---- TranscodeDxt1ToEtc1 in the palette domain (r04).  dxtc_to_etc_transcoder.cc:29-40 decodes the DXT1 block and runs
+// EncodeEtc1Block(kHeuristic) on the 16 pixels.  The pixels are four colours at most, so everything kHeuristic computes
+// follows from the palette and the 2-bit indices without materialising a pixel:
+//   * quadrant sums / deviation sums (etc.cc:299-312, 415-455, 553-574) from the channel planes through the quad selectors
+//     (as in dxt_downsample_2x2); the reference's "(2,2) twice, never (3,3)" quadrant is one weighted v_dot4;
+//   * ComputeCodewordError (etc.cc:350-385) for the FOUR palette colours instead of the eight pixels of a sub-block: 16 keys
+//     per sub-block instead of 32, same keys and tie rule as eval_codeword;
+//   * the pixels' new 2-bit indices are a 4-entry table look-up of their old ones, done on bit planes: the DXT index bits
+//     are gathered straight into ETC bit order (bit 4x + y, etc.cc:131-137) by v_dot4 with power-of-two weights, and the
+//     table look-up is three v_bfi per plane and sub-block.
+// Bit-exact with decode_dxt_colors + encode_etc1_block(px, 3) (checked block by block in tests/host_emul).
+ICAMD_DEV Out8 transcode_dxt1_block_to_etc1(uint32_t w0, uint32_t bits) {
+  uint32_t P[3];
+  dxt_palette_planes(w0, false, P);
+  // the four palette colours as pixels (R | G << 8 | B << 16)
+  const uint32_t t01 = perm(P[1], P[0], 0x05010400u), t23 = perm(P[1], P[0], 0x07030602u);  // R G R G of entries (0, 1) / (2, 3)
+  const uint32_t col[4] = { perm(P[2], t01, 0x0c040100u), perm(P[2], t01, 0x0c050302u),
+                            perm(P[2], t23, 0x0c060100u), perm(P[2], t23, 0x0c070302u) };
+  // quadrant q = 2 (y >= 2) + (x >= 2): its four bytes of each channel, and their sums
+  const uint32_t rows01 = perm(0u, bits, 0x0c010c00u), rows23 = perm(0u, bits, 0x0c030c02u);
+  const uint32_t sel[4] = { dxt_quad_selector<0>(rows01), dxt_quad_selector<1>(rows01),
+                            dxt_quad_selector<0>(rows23), dxt_quad_selector<1>(rows23) };
+  uint32_t qpk[4][3], qs[4][3];
+  ICAMD_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    ICAMD_UNROLL
+    for (int ch = 0; ch < 3; ++ch) {
+      qpk[q][ch] = perm(P[ch], P[ch], sel[q]);
+      qs[q][ch] = sad_u8(qpk[q][ch], 0u, 0u);
+    }
+  }
+  // the partition (etc.cc:553-574): the fourth quadrant sum uses pixel (2,2) twice and never (3,3) -- quad byte 0 twice,
+  // byte 3 not at all
+  uint32_t e_lr = 0, e_tb = 0;
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    const uint32_t q3 = udot4(qpk[3][ch], 0x00010102u, 0u);
+    const uint32_t l = (qs[0][ch] + qs[2][ch]) >> 3, r = (qs[1][ch] + q3) >> 3;
+    const uint32_t t = (qs[0][ch] + qs[1][ch]) >> 3, b = (qs[2][ch] + q3) >> 3;
+    const uint32_t dlr = sad_u32(l, r, 0u), dtb = sad_u32(t, b, 0u);
+    e_lr = umad24(dlr, dlr, e_lr);
+    e_tb = umad24(dtb, dtb, e_tb);
+  }
+  const bool flip = !(e_lr > e_tb);
+  // sub-block sums and channel bytes: left | right = quadrants (0, 2) | (1, 3), top | bottom = (0, 1) | (2, 3)
+  uint32_t s0[3], s1[3], pk[2][3][2];
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    const uint32_t mid0 = flip ? qs[1][ch] : qs[2][ch], mid1 = flip ? qs[2][ch] : qs[1][ch];
+    s0[ch] = qs[0][ch] + mid0;
+    s1[ch] = mid1 + qs[3][ch];
+    pk[0][ch][0] = qpk[0][ch];
+    pk[0][ch][1] = flip ? qpk[1][ch] : qpk[2][ch];
+    pk[1][ch][0] = flip ? qpk[2][ch] : qpk[1][ch];
+    pk[1][ch][1] = qpk[3][ch];
+  }
+  // FindBestSubblockEncoding's base colours (etc.cc:460-542), as encode_flip computes them
+  uint32_t q5a[3], q5b[3];
+  bool diff_mode = true;
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    q5a[ch] = s0[ch] >> 6;
+    q5b[ch] = s1[ch] >> 6;
+    const int32_t d = (int32_t)q5b[ch] - (int32_t)q5a[ch];
+    diff_mode = diff_mode && d >= -4 && d <= 3;
+  }
+  uint32_t hi = flip ? 1u : 0u, b0[3], b1[3];
+  if (diff_mode) hi |= 2u;
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    const uint32_t d3 = (q5b[ch] - q5a[ch]) & 7u, qa = s0[ch] >> 7, qb = s1[ch] >> 7;
+    hi |= diff_mode ? (q5a[ch] << (27 - 8 * ch) | d3 << (24 - 8 * ch)) : (qa << (28 - 8 * ch) | qb << (24 - 8 * ch));
+    b0[ch] = diff_mode ? ((q5a[ch] << 3) | (q5a[ch] >> 2)) : qa * 17u;
+    b1[ch] = diff_mode ? ((q5b[ch] << 3) | (q5b[ch] >> 2)) : qb * 17u;
+  }
+  // per sub-block: FindCodewordHeuristic (etc.cc:415-455), then the best modifier of each PALETTE colour
+  uint32_t fld[2][4];  // 32 E + (3 - k) of the winner; bits 0-1 = 3 - k
+  uint32_t cws[2];
+  ICAMD_UNROLL
+  for (int sb = 0; sb < 2; ++sb) {
+    const uint32_t *bc = sb ? b1 : b0;
+    const EtcBase base = { bc[0] << 24 | bc[2] << 8, bc[1] << 8 };
+    const uint32_t br4 = perm(0u, bc[0], 0u), bg4 = perm(0u, bc[1], 0u), bb4 = perm(0u, bc[2], 0u);  // byte 0 replicated (a plain multiply is a quarter-rate v_mul_lo_u32)
+    const uint32_t sr = sad_u8(pk[sb][0][0], br4, sad_u8(pk[sb][0][1], br4, 0u));
+    const uint32_t sg = sad_u8(pk[sb][1][0], bg4, sad_u8(pk[sb][1][1], bg4, 0u));
+    const uint32_t sbl = sad_u8(pk[sb][2][0], bb4, sad_u8(pk[sb][2][1], bb4, 0u));
+    const uint32_t dev = umax3(sr >> 3, sg >> 3, sbl >> 3);
+    const uint32_t cw = (dev > 144u) + (dev > 93u) + (dev > 70u) + (dev > 51u) + (dev > 35u) + (dev > 23u) + (dev > 12u);
+    const uint32_t sh = (cw & 3u) * 8u;
+    const uint32_t a = bfe(cw < 4u ? kEtcModA_lo : kEtcModA_hi, sh, 8), b = bfe(cw < 4u ? kEtcModB_lo : kEtcModB_hi, sh, 8);
+    uint32_t v[4];
+    int32_t c[4];
+    build_candidates(base, a, b, v, c);
+    ICAMD_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const int32_t k0 = (int32_t)(udot4(col[i], v[0], 0u) << 6) + c[0];
+      const int32_t k1 = (int32_t)(udot4(col[i], v[1], 0u) << 6) + c[1];
+      const int32_t k2 = (int32_t)(udot4(col[i], v[2], 0u) << 6) + c[2];
+      const int32_t k3 = (int32_t)(udot4(col[i], v[3], 0u) << 6) + c[3];
+      fld[sb][i] = (uint32_t)imax(imax3(k0, k1, k2), k3);
+    }
+    cws[sb] = cw;
+  }
+  hi |= cws[0] << 5 | cws[1] << 2;
+  // old index bits in ETC order: plane bit 4x + y = bit of pixel (x, y).  Column x of the low (high) index bit sits at bit
+  // 2x (2x + 1) of each row's byte: mask it, and a v_dot4 with weights 2^(y + 2x') drops the column's four bits at its
+  // nibble (two columns per pass so that the weights stay below 256; the upper two columns come from `bits >> 4`).
+  const uint32_t bl = bits, bh = bits >> 1, bl4 = bits >> 4, bh4 = bits >> 5;
+  const uint32_t L = udot4(bl & 0x04040404u, 0x20100804u, udot4(bl & 0x01010101u, 0x08040201u, 0u)) |
+                     udot4(bl4 & 0x04040404u, 0x20100804u, udot4(bl4 & 0x01010101u, 0x08040201u, 0u)) << 8;
+  const uint32_t H = udot4(bh & 0x04040404u, 0x20100804u, udot4(bh & 0x01010101u, 0x08040201u, 0u)) |
+                     udot4(bh4 & 0x04040404u, 0x20100804u, udot4(bh4 & 0x01010101u, 0x08040201u, 0u)) << 8;
+  // table look-up on the planes: field (3 - k) bit B of the pixel = fld[S][old index] bit B.  mask(x) = all ones iff the bit
+  // is set (v_bfe_i32 of a 1-bit field); v_bfi(m, a, b) = (m & a) | (~m & b) picks by the old index's bits.
+  uint32_t plane[2][2];  // [sub-block][bit of 3 - k]
+  ICAMD_UNROLL
+  for (int sb = 0; sb < 2; ++sb) {
+    ICAMD_UNROLL
+    for (int bit = 0; bit < 2; ++bit) {
+      uint32_t m[4];
+      ICAMD_UNROLL
+      for (int i = 0; i < 4; ++i) m[i] = bit_mask(fld[sb][i], (uint32_t)bit);
+      const uint32_t lo2 = (L & m[1]) | (~L & m[0]), hi2 = (L & m[3]) | (~L & m[2]);
+      plane[sb][bit] = (H & hi2) | (~H & lo2);
+    }
+  }
+  // sub-block 1 owns x >= 2 (bits 8-15) for flip = 0, y >= 2 (bits 2, 3 of every nibble) for flip = 1
+  const uint32_t r1 = flip ? 0xccccu : 0xff00u;
+  const uint32_t f_lsb = (r1 & plane[1][0]) | (~r1 & plane[0][0]), f_msb = (r1 & plane[1][1]) | (~r1 & plane[0][1]);
+  // index k = 3 - field: both bits inverted; LSB plane in bits 0-15, MSB plane in bits 16-31 (etc.cc:150-156)
+  const uint32_t lo = ~((f_lsb & 0xffffu) | f_msb << 16);
+  Out8 o = { perm(0u, hi, 0x00010203u), perm(0u, lo, 0x00010203u) };
+  return o;
+}
+
 // Decode any block (DXT1 / DXT5 / ETC1, codec ids of ic_amd.h) to packed pixels, no red/blue swap
 // (Downsample and the transcoder always pass swap = false).
 template <int CODEC>

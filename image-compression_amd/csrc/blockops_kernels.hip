@@ -158,9 +158,8 @@ extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_to
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
   if (k >= n) return;
   const uint2 b = blocks[k];
-  uint32_t px[16];
-  decode_dxt_colors(b.x, b.y, false, false, px);          // DecodeDxt1Block(block, swap = false)
-  const Out8 o = encode_etc1_block(px, 3u);               // EncodeEtc1Block(..., kHeuristic)
+  // DecodeDxt1Block(block, swap = false) + EncodeEtc1Block(..., kHeuristic), without materialising the pixels
+  const Out8 o = transcode_dxt1_block_to_etc1(b.x, b.y);
   blocks[k] = make_uint2(o.lo, o.hi);
 }
 

@@ -364,7 +364,7 @@ ICAMD_DEV EtcSubResult heuristic_codeword(const uint32_t px[16], const EtcBase &
                                           uint32_t bb, const uint32_t (*packed)[2] = nullptr) {
   uint32_t sr = 0, sg = 0, sb = 0;
   if (packed) {
-    const uint32_t br4 = br * 0x01010101u, bg4 = bg * 0x01010101u, bb4 = bb * 0x01010101u;  // (<= 255: no carries)
+    const uint32_t br4 = perm(0u, br, 0u), bg4 = perm(0u, bg, 0u), bb4 = perm(0u, bb, 0u);  // byte 0 replicated (a plain multiply is a quarter-rate v_mul_lo_u32)
     sr = sad_u8(packed[0][0], br4, sad_u8(packed[0][1], br4, 0u));
     sg = sad_u8(packed[1][0], bg4, sad_u8(packed[1][1], bg4, 0u));
     sb = sad_u8(packed[2][0], bb4, sad_u8(packed[2][1], bb4, 0u));

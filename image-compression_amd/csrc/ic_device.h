@@ -105,6 +105,7 @@ ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
   return r;
 }
 ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return (v >> off) & ((1u << w) - 1u); }
+ICAMD_DEV uint32_t bit_mask(uint32_t v, uint32_t bit) { return (v >> bit) & 1u ? 0xffffffffu : 0u; }
 ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return a * b + c; }
 ICAMD_DEV uint32_t umad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
 ICAMD_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -134,6 +135,8 @@ ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __bu
 // (selector 0..3 -> lo bytes, 4..7 -> hi bytes, 0x0c -> 0x00).
 ICAMD_DEV uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 ICAMD_DEV uint32_t bfe(uint32_t v, uint32_t off, uint32_t w) { return __builtin_amdgcn_ubfe(v, off, w); }
+// v_bfe_i32 of a one-bit field: all ones iff bit `bit` of v is set
+ICAMD_DEV uint32_t bit_mask(uint32_t v, uint32_t bit) { return (uint32_t)__builtin_amdgcn_sbfe((int32_t)v, bit, 1u); }
 // v_mad_i32_i24: a * b + c.  PRECONDITION |a|, |b| < 2^23 (the compiler cannot prove it and would emit
 // v_mul_lo_u32 + v_add_u32 for the plain expression).
 ICAMD_DEV int32_t imad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }

@@ -208,6 +208,24 @@ def test_blockops_math_matches_oracle(emul):
     want = T.oracle_transcode(raw.tobytes())
     emul.emul_transcode(raw.ctypes.data, raw.size)
     assert raw.tobytes() == want
+    # the palette-domain transcoder (transcode_dxt1_block_to_etc1) on more kinds of blocks: 64 k random words, three-colour
+    # mode (c0 < c1), equal endpoints, all-one-index blocks, and the encoder's own output for every synthetic content
+    cases = [g.integers(0, 256, size=8 * 65536, dtype=np.uint8)]
+    r = g.integers(0, 256, size=(8192, 8), dtype=np.uint8)
+    r[:, :4] = np.sort(r[:, :4].copy().view(np.uint16), axis=1).view(np.uint8)
+    cases.append(r.reshape(-1).copy())
+    r = g.integers(0, 256, size=(8192, 8), dtype=np.uint8)
+    r[:, 2:4] = r[:, 0:2]
+    cases.append(r.reshape(-1).copy())
+    r = g.integers(0, 256, size=(4096, 8), dtype=np.uint8)
+    r[:, 4:] = np.repeat(np.array([0x00, 0x55, 0xaa, 0xff], np.uint8), 1024)[:, None]
+    cases.append(r.reshape(-1).copy())
+    for gen in ("noise", "smooth", "flat", "mixed"):
+        cases.append(np.frombuffer(T.oracle_compress(T.DXTC, T.RGB, T.GENERATORS[gen](128, 128, 3, index=11), 128, 128), np.uint8).copy())
+    for raw in cases:
+        want = T.oracle_transcode(raw.tobytes())
+        emul.emul_transcode(raw.ctypes.data, raw.size)
+        assert raw.tobytes() == want
 
 
 def test_random_soak_host_emulation(emul):
