@@ -197,6 +197,12 @@ ICAMD_DEV int32_t eval_codeword_mixed(const uint32_t px[16], const uint32_t abs2
 // veto the shortcut, the tier or a pruning step for everyone (a saturated flat colour, typically) no longer does.
 // (SKIP is a template parameter so that waves without such lanes run exactly the code they ran before: r03 A/B, a run-time
 // flag alone cost noise content 5 %.)
+// ICAMD_ETC1_NO_PSUM (A/B only): recompute 2 (r + g + b) of a pixel where it is used instead of keeping 16 of them live
+#if defined(ICAMD_ETC1_NO_PSUM)
+#define ICAMD_PSUM(q) udot4(px[q], 0x00020202u, 0u)
+#else
+#define ICAMD_PSUM(q) psum[q]
+#endif
 template <int FLIP, int S, bool TIER, bool PRUNE, bool SKIP = false>
 ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t psum[16], const EtcBase &base,
                                         const uint32_t bch[3], const uint32_t sub_sum[3], bool skip_lane = false) {
@@ -218,7 +224,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
   if (fast) {
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) {
-      abs2[j] = sad_u32(psum[sub_pixel<FLIP, S>(j)], bsum2, 0u);
+      abs2[j] = sad_u32(ICAMD_PSUM((sub_pixel<FLIP, S>(j))), bsum2, 0u);
       s2 += abs2[j];
     }
     // Sum_j E0 = 2 * (base . sub_sum) - 8 |base|^2 : puts the shortcut's scores on the scale of eval_codeword
@@ -253,7 +259,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     ICAMD_UNROLL
     for (int j = 0; j < 8; ++j) {
       const uint32_t q = sub_pixel<FLIP, S>(j);
-      const int32_t neg = (int32_t)(psum[q] - bsum2) >> 31;  // -1 iff s < 0
+      const int32_t neg = (int32_t)(ICAMD_PSUM(q) - bsum2) >> 31;  // -1 iff s < 0
       k0[j] = (int32_t)(udot4(px[q], base_px, 0u) << 6) + c3 + 2 * neg;
     }
   }
@@ -348,7 +354,7 @@ ICAMD_DEV EtcSubResult search_codewords(const uint32_t px[16], const uint32_t ps
     uint32_t acc = 0;
     ICAMD_UNROLL
     for (int j = 7; j >= 0; --j) {
-      acc = alignbit(acc, psum[sub_pixel<FLIP, S>(j)] - bsum2, 31);  // s < 0
+      acc = alignbit(acc, ICAMD_PSUM((sub_pixel<FLIP, S>(j))) - bsum2, 31);  // s < 0
       acc = alignbit(acc, thr - abs2[j], 31);                          // 2|s| > 3 (a + b): magnitude b
     }
     r.fields = won_fast ? ~acc << 16 : r.fields;

@@ -65,9 +65,27 @@ __device__ __forceinline__ Out8 etc1_encode_classified(const uint32_t px[16], bo
 #define ICAMD_ETC1_REGROUP 0
 #endif
 
+// Lane -> block inside a 16 x 16-block tile.  ICAMD_ETC1_WAVE_8X8: a wave covers 8 x 8 blocks (32 x 32 pixels) instead of
+// 16 x 4 (64 x 16 pixels): more compact content per wave-uniform decision, 96- instead of 192-byte row segments per wave.
+#ifndef ICAMD_ETC1_WAVE_8X8
+#define ICAMD_ETC1_WAVE_8X8 0
+#endif
+__device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
+  TileCoord t = locate_tile<false>(P);
+  if (ICAMD_ETC1_WAVE_8X8 && P.log2_tile_cols == 4u) {
+    const uint32_t tid = threadIdx.x;
+    t.lx = (tid & 7u) + ((tid >> 6) & 1u) * 8u;
+    t.ly = ((tid >> 3) & 7u) + (tid >> 7) * 8u;
+    t.bcol = t.bcol0 + t.lx;
+    t.brow = t.brow0 + t.ly;
+    t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
+  }
+  return t;
+}
+
 template <int COMPS, int STRATEGY>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = locate_tile<false>(P);
+  const TileCoord t = etc1_locate_tile(P);
   if (STRATEGY == 3 || !ICAMD_ETC1_REGROUP) {
     if (!t.valid) return;
     uint32_t px[16];
@@ -180,7 +198,13 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   // 16 x 16-block tiles (a wave = 16 x 4 blocks = 64 x 16 pixels) instead of 256 x 1: the encoder's wave-uniform
   // decisions (unclamped shortcut, codeword pruning) fire far more often on compact waves, and at 7 % of the HBM
   // roofline the narrower loads cost nothing: noise 1.47 = 1.47 ms, smooth 1.85 -> 1.61 ms, flat 1.90 -> 1.72 ms (r01)
-  const uint32_t cap = 4u;
+  // (RGB888: a 16-block tile row is 192 bytes -- it straddles 128-byte lines that the neighbouring tile reads too, and the
+  //  counters show 1.29 x the algorithmic bytes; 32 x 8-block tiles make it 384 bytes = three whole lines:
+  //  ICAMD_ETC1_RGB888_TILE_LOG2, A/B in profiles/r04_ab_etc1_tiles_waves.log: traffic 1.33 -> 1.00 x but smooth -21 %, flat -17 %: a wave becomes 32 x 2 blocks)
+#ifndef ICAMD_ETC1_RGB888_TILE_LOG2
+#define ICAMD_ETC1_RGB888_TILE_LOG2 4u
+#endif
+  const uint32_t cap = comps == 3 ? ICAMD_ETC1_RGB888_TILE_LOG2 : 4u;
   typedef void (*Kernel)(GridParams);
   static const Kernel kernels[2][4] = {
     { icamd_etc1_rgb888_split_h_kernel, icamd_etc1_rgb888_split_v_kernel, icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_heuristic_kernel },
