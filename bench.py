@@ -154,13 +154,13 @@ def make_batch(torch, content, batch, size, comps, device, seed, height=None, ro
             keep = torch.randint(0, 8, (batch, h, size), dtype=torch.int32, device=device, generator=g) != 0
             chans.append(torch.where(keep, torch.full_like(a, 255), a))
         return torch.stack(chans, dim=-1).to(torch.uint8).contiguous()
-    th = (h + 15) // 16
-    tiles = torch.randint(0, 256, (batch, th, size // 16, comps), dtype=torch.uint8, device=device, generator=g)
+    th, tw = (h + 15) // 16, (size + 15) // 16
+    tiles = torch.randint(0, 256, (batch, th, tw, comps), dtype=torch.uint8, device=device, generator=g)
     img = tiles.repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)
-    noisy = (torch.randint(0, 8, (batch, th, size // 16, 1), device=device, generator=g) == 0)
+    noisy = (torch.randint(0, 8, (batch, th, tw, 1), device=device, generator=g) == 0)
     noisy = noisy.repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)
     noise = torch.randint(0, 256, img.shape, dtype=torch.uint8, device=device, generator=g)
-    return torch.where(noisy, noise, img)[:, :h].contiguous()
+    return torch.where(noisy, noise, img)[:, :h, :size].contiguous()
 
 
 def cpu_baseline(T, codec, comps, size, strategy, host_img):

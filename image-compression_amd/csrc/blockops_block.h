@@ -276,6 +276,81 @@ ICAMD_DEV void etc1_downsample_2x2(const uint32_t *const s[2][2], uint32_t px[16
   }
 }
 
+// ---- the block DECODERS on the same planes (r04): a pixel ROW's four indices become one selector, one v_perm per channel
+// looks the row up, and two v_perm per output dword interleave the channels in memory order -- the 16 pixels of a block are
+// never selected one by one (decode_dxt_colors / decode_dxt5_alpha / decode_etc1 spend 7-16 instructions per pixel on 4- and
+// 8-way selects).  Same bytes as those functions (checked block by block in tests/host_emul).
+//
+// Selector of pixel row y of a DXT colour block: byte x = 2-bit index of pixel (x, y).
+ICAMD_DEV uint32_t dxt_row_selector(uint32_t bits, int y) {
+  const uint32_t v = bfe(bits, 8u * (uint32_t)y, 8u);
+  const uint32_t t = v | v << 12;
+  return (t | t << 6) & 0x03030303u;
+}
+// Selector of pixel row y of a DXT5 alpha block: byte x = 3-bit code of pixel (x, y).  lo24 / hi24 = codes of pixels 0-7 / 8-15.
+ICAMD_DEV uint32_t dxt5_row_alpha_selector(uint32_t lo24, uint32_t hi24, int y) {
+  const uint32_t h = y < 2 ? lo24 : hi24, x = (y & 1) ? h >> 12 : h;
+  const uint32_t t = (x & 0x3fu) | bfe(x, 6, 6) << 16;
+  return (t | t << 5) & 0x07070707u;
+}
+// Selector of pixel row y of an ETC1 block for v_perm over {palette of sub-block 1, palette of sub-block 0}: byte x = modifier
+// index of pixel (x, y) + 4 if the pixel belongs to sub-block 1.  lo = big-endian index word (bit 4x + y: LSB, + 16: MSB).
+ICAMD_DEV uint32_t etc1_row_selector(uint32_t lo, int y, bool flip) {
+  const uint32_t w = (y ? lo >> y : lo) & 0x11111111u;                       // bits 0, 4, 8, 12 (LSBs) and 16, 20, 24, 28 (MSBs)
+  const uint32_t l = perm(0u, w, 0x0c010c00u), m = perm(0u, w, 0x0c030c02u);  // bits 0, 4, 16, 20 of each
+  const uint32_t lb = (l | l << 4) & 0x01010101u, mb = (m | m << 4) & 0x01010101u;
+  const uint32_t sub = flip ? (y >= 2 ? 0x04040404u : 0u) : 0x04040000u;     // sub-block 1: y >= 2 (flip) / x >= 2
+  return lb | mb << 1 | sub;
+}
+// Interleave three planar rows (bytes x = 0..3 of each channel) into the 12 bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3.
+ICAMD_DEV void interleave_rgb_row(uint32_t r, uint32_t g, uint32_t b, uint32_t out[3]) {
+  out[0] = perm(b, perm(g, r, 0x010c0400u), 0x03040100u);   // [R0 G0 .. R1] then B0 into byte 2
+  out[1] = perm(r, perm(b, g, 0x020c0501u), 0x03060100u);   // [G1 B1 .. G2] then R2 into byte 2
+  out[2] = perm(g, perm(r, b, 0x030c0702u), 0x03070100u);   // [B2 R3 .. B3] then G3 into byte 2
+}
+// ... and four planar rows into the four R G B A pixels of the row.
+ICAMD_DEV void interleave_rgba_row(uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t out[4]) {
+  const uint32_t rg01 = perm(g, r, 0x05010400u), rg23 = perm(g, r, 0x07030602u);
+  const uint32_t ba01 = perm(a, b, 0x05010400u), ba23 = perm(a, b, 0x07030602u);
+  out[0] = perm(ba01, rg01, 0x05040100u);
+  out[1] = perm(ba01, rg01, 0x07060302u);
+  out[2] = perm(ba23, rg23, 0x05040100u);
+  out[3] = perm(ba23, rg23, 0x07060302u);
+}
+// A whole block to its four pixel rows in output memory order: rows[y][0..2] = the 12 bytes of an RGB888 row (CODEC 0: DXT1,
+// 2: ETC1), rows[y][0..3] = the four RGBA pixels (CODEC 1: DXT5).  swap: stored R goes to the third byte (kBGR / kBGRA).
+template <int CODEC>
+ICAMD_DEV void decode_block_rows(const uint32_t *w, bool swap, uint32_t rows[4][4]) {
+  if (CODEC == 2) {
+    uint32_t P[2][3];
+    const bool flip = etc1_palette_planes(w[0], P);
+    const uint32_t lo = perm(0u, w[1], 0x00010203u);
+    ICAMD_UNROLL
+    for (int y = 0; y < 4; ++y) {
+      const uint32_t sel = etc1_row_selector(lo, y, flip);
+      interleave_rgb_row(perm(P[1][0], P[0][0], sel), perm(P[1][1], P[0][1], sel), perm(P[1][2], P[0][2], sel), rows[y]);
+    }
+    return;
+  }
+  uint32_t P[3];
+  dxt_palette_planes(CODEC == 1 ? w[2] : w[0], CODEC == 1, P);
+  const uint32_t bits = CODEC == 1 ? w[3] : w[1];
+  const uint32_t pr = swap ? P[2] : P[0], pb = swap ? P[0] : P[2];
+  uint32_t tlo = 0, thi = 0, lo24 = 0, hi24 = 0;
+  if (CODEC == 1) {
+    dxt5_alpha_planes(w[0], tlo, thi);
+    lo24 = w[0] >> 16 | (w[1] & 0xffu) << 16;
+    hi24 = w[1] >> 8;
+  }
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const uint32_t sel = dxt_row_selector(bits, y);
+    const uint32_t r = perm(pr, pr, sel), g = perm(P[1], P[1], sel), b = perm(pb, pb, sel);
+    if (CODEC == 1) interleave_rgba_row(r, g, b, perm(thi, tlo, dxt5_row_alpha_selector(lo24, hi24, y)), rows[y]);
+    else interleave_rgb_row(r, g, b, rows[y]);
+  }
+}
+
 // ---- TranscodeDxt1ToEtc1 in the palette domain (r04).  dxtc_to_etc_transcoder.cc:29-40 decodes the DXT1 block and runs
 // EncodeEtc1Block(kHeuristic) on the 16 pixels.  The pixels are four colours at most, so everything kHeuristic computes
 // follows from the palette and the 2-bit indices without materialising a pixel:

@@ -1,7 +1,7 @@
 // decode_kernels.hip -- DXT1 / DXT5 / ETC1 decode kernels for gfx950 ("next" row 8f.1): one block per
 // lane, 8/16-byte coalesced block loads, 12/16-byte row-segment stores (Compressor4x4Helper::Decompress,
 // internal/compressor4x4_helper.h:218-262: blocks past the image edge are clipped).
-#include "decode_block.h"
+#include "blockops_block.h"  // decode_block.h + the palette-plane row decoders
 #include "ic_launch.h"
 #include "ic_amd.h"
 
@@ -14,34 +14,42 @@ __device__ __forceinline__ void decode_one(const DecodeParams &P, uint32_t k) {
   const uint32_t rem = k - img * P.blocks_per_image;
   const uint32_t brow = fastdiv(rem, P.div_cols), bcol = rem - brow * P.block_cols;
   const uint8_t *src = P.blocks + (size_t)img * P.src_image_stride + (size_t)rem * (CODEC == ICAMD_DXT5 ? 16 : 8);
-  uint32_t px[16];
   const bool swap = P.swap_rb != 0;
+  uint32_t w[4] = { 0, 0, 0, 0 };
   if (CODEC == ICAMD_DXT5) {
-    const U4 w = *reinterpret_cast<const U4 *>(src);  // no alignment assumed: the caller owns the block pointer
-    decode_dxt_colors(w.z, w.w, swap, true, px);
-    decode_dxt5_alpha(w.x, w.y, px);
+    const U4 v = *reinterpret_cast<const U4 *>(src);  // no alignment assumed: the caller owns the block pointer
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
   } else {
-    const U2 w = *reinterpret_cast<const U2 *>(src);
-    if (CODEC == ICAMD_DXT1) decode_dxt_colors(w.x, w.y, swap, false, px);
-    else decode_etc1(w.x, w.y, px);
+    const U2 v = *reinterpret_cast<const U2 *>(src);
+    w[0] = v.x; w[1] = v.y;
   }
   uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride;
   const uint32_t row = brow * 4, col = bcol * 4;
   if (row + 4 <= P.height && col + 4 <= P.width) {
+    // whole block inside the image: rows straight in memory order from the palette planes (blockops_block.h)
+    uint32_t rows[4][4];
+    decode_block_rows<CODEC>(w, swap, rows);
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
       uint8_t *q = dst + (size_t)(row + y) * P.row_stride + (size_t)col * COMPS;
       if (COMPS == 4) {
-        U4 v = { px[4 * y], px[4 * y + 1], px[4 * y + 2], px[4 * y + 3] };
+        U4 v = { rows[y][0], rows[y][1], rows[y][2], rows[y][3] };
         *reinterpret_cast<U4 *>(q) = v;
       } else {
-        const uint32_t a = px[4 * y] & 0xffffffu, b = px[4 * y + 1] & 0xffffffu, c = px[4 * y + 2] & 0xffffffu,
-                       d = px[4 * y + 3] & 0xffffffu;
-        U3 v = { a | b << 24, b >> 8 | c << 16, c >> 16 | d << 8 };
+        U3 v = { rows[y][0], rows[y][1], rows[y][2] };
         *reinterpret_cast<U3 *>(q) = v;
       }
     }
-  } else {
+  } else {  // clipped at the image's edge (helper.h:218-262): pixel by pixel
+    uint32_t px[16];
+    if (CODEC == ICAMD_DXT5) {
+      decode_dxt_colors(w[2], w[3], swap, true, px);
+      decode_dxt5_alpha(w[0], w[1], px);
+    } else if (CODEC == ICAMD_DXT1) {
+      decode_dxt_colors(w[0], w[1], swap, false, px);
+    } else {
+      decode_etc1(w[0], w[1], px);
+    }
 #pragma unroll
     for (int y = 0; y < 4; ++y)
 #pragma unroll

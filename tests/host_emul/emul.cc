@@ -85,6 +85,17 @@ extern "C" int emul_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t
       if (codec == 1) { decode_dxt_colors(b[2], b[3], swap != 0, true, px); decode_dxt5_alpha(b[0], b[1], px); }
       else if (codec == 0) decode_dxt_colors(b[0], b[1], swap != 0, false, px);
       else decode_etc1(b[0], b[1], px);
+      {  // the row decoders the kernels use for whole blocks (palette planes) must give the same bytes
+        uint32_t rows[4][4];
+        if (codec == 1) decode_block_rows<1>(b, swap != 0, rows);
+        else if (codec == 0) decode_block_rows<0>(b, swap != 0, rows);
+        else decode_block_rows<2>(b, false, rows);
+        for (int y = 0; y < 4; ++y) {
+          uint8_t want[16];
+          for (int x = 0; x < 4; ++x) memcpy(want + x * comps, &px[4 * y + x], comps);
+          if (memcmp(want, rows[y], 4 * comps) != 0) return 0;
+        }
+      }
       for (uint32_t y = 0; y < 4 && br * 4 + y < h; ++y)
         for (uint32_t x = 0; x < 4 && bc * 4 + x < w; ++x)
           memcpy(out + (br * 4 + y) * stride + (size_t)(bc * 4 + x) * comps, &px[4 * y + x], comps);

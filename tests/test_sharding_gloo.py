@@ -195,8 +195,11 @@ def _slab_worker(rank, world, port, results):
     ok = True
     for workload, size, content in (("dxt1_rgba8", 64, "noise"), ("dxt5_rgba8", 40, "smooth"), ("dxt1_rgb888", 12, "flat")):
         res = bench.slab_leg(ctx, _OraclePkg, sh, workload, size, 2, content)
-        ok &= res["parity"].startswith("bit-exact") and res.get("value_with_gather") is not None and res["scaling"] == "strong"
-        ok &= sum(res["slab_block_rows"]) == (size + 3) // 4
+        good = res["parity"].startswith("bit-exact") and res.get("value_with_gather") is not None and res["scaling"] == "strong" \
+            and sum(res["slab_block_rows"]) == (size + 3) // 4
+        if not good:
+            print("slab_leg failed on rank %d: %r" % (rank, res), file=sys.stderr, flush=True)
+        ok &= good
     # a corrupted encoder must be caught by the slab check
     class Bad(_OraclePkg):
         @staticmethod
