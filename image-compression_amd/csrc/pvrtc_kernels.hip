@@ -381,6 +381,48 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
 #pragma unroll
       for (uint32_t r = 0; r + 1 < kRowRing; ++r) dma_row(r);
     }
+#if defined(ICAMD_PVRTC_FUSION_PROBE)
+    // r04 measurement aid, NEVER in the shipped library: what would one pass over the pixels cost in situ?  Every pixel row the
+    // strip consumes also feeds the morph reduction of its block (the five axes' first-min / first-max keys); every fourth row
+    // the block is finished like pvrtc_extremes does it (ten data-dependent pixel look-ups -- here from the row ring --, five
+    // v_sad_u8, the best-axis scan, the brightness order, two channel reductions).  The results are only kept alive, not used:
+    // the encode kernel's output is unchanged, its time shows the VALU / register price of fusing the morph in.
+    uint32_t pr_lmin = 0xffffffffu, pr_lmax = 0u, pr_rbmin = 0xffffffffu, pr_rbmax = 0u, pr_gamin = 0xffffffffu, pr_gamax = 0u, pr_acc = 0u;
+    auto probe_row = [&](uint32_t r, const uint32_t *pixels) {
+      const uint32_t q = r & 3u;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const uint32_t c = pixels[x], i = (uint32_t)(x & 3);
+        const uint32_t idx4 = (8u * q + (uint32_t)(x & 4)) * 0x01010101u + 0x03020100u;
+        const uint32_t up1 = 31u - 2u * (8u * q + (uint32_t)x), up = up1 * 0x00010001u;
+        const uint32_t kl = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
+        const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16), k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
+        pr_rbmin = pk_min_u16(pr_rbmin, k_rb); pr_gamin = pk_min_u16(pr_gamin, k_ga);
+        pr_rbmax = pk_max_u16(pr_rbmax, k_rb + up); pr_gamax = pk_max_u16(pr_gamax, k_ga + up);
+        pr_lmin = umin(pr_lmin, kl); pr_lmax = umax(pr_lmax, kl + up1);
+      }
+      if (q == 3u) {
+        const uint32_t kmin[5] = { pr_lmin, pr_rbmin & 0xffffu, pr_gamin & 0xffffu, pr_rbmin >> 16, pr_gamin >> 16 };
+        const uint32_t kmax[5] = { pr_lmax, pr_rbmax & 0xffffu, pr_gamax & 0xffffu, pr_rbmax >> 16, pr_gamax >> 16 };
+        uint32_t best_diff = 0, best_lo = 0, best_hi = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+          uint32_t lo, hi;
+          const uint32_t i0 = kmin[a] & 31u, i1 = 31u - (kmax[a] & 31u);
+          const uint32_t a0 = ring_lane_byte + (i0 >> 3) * 2048u + ((i0 >> 2) & 1u) * 1024u + (i0 & 3u) * 4u;
+          const uint32_t a1 = ring_lane_byte + (i1 >> 3) * 2048u + ((i1 >> 2) & 1u) * 1024u + (i1 & 3u) * 4u;
+          asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+          hi = (kmax[a] >> 8) == 0u ? img[0] * 0u + lo : hi;
+          const uint32_t d = sad_u8(lo, hi, 0u);
+          const bool better = (a == 0) || d > best_diff;
+          best_lo = better ? lo : best_lo; best_hi = better ? hi : best_hi; best_diff = better ? d : best_diff;
+        }
+        const bool swap = udot4(best_hi, 0x01010101u, 0u) < udot4(best_lo, 0x01010101u, 0u);
+        pr_acc ^= channel_reduce(swap ? best_hi : best_lo, false) + channel_reduce(swap ? best_lo : best_hi, true);
+        pr_lmin = pr_rbmin = pr_gamin = 0xffffffffu; pr_lmax = pr_rbmax = pr_gamax = 0u;
+      }
+    };
+#endif
     auto load_px = [&](uint32_t r, uint32_t *pixels, uint32_t *right_px) {
       if (DMA) {
         // rows r + 1 and r + 2 (four DMA instructions) may still be in flight; row r and everything older has landed
@@ -392,6 +434,9 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
         pixels[4] = v1.x; pixels[5] = v1.y; pixels[6] = v1.z; pixels[7] = v1.w;
         // the slot of row r - 1 (read one call ago, its ds_reads long complete) takes row r + 3
         dma_row(r + kRowRing - 1u);
+#if defined(ICAMD_PVRTC_FUSION_PROBE)
+        probe_row(r, pixels);
+#endif
         return;
       }
       // n = 2^log2_n <= 32 768: the pixel index fits 32 bits -- a shift, not a 64-bit multiply
@@ -457,6 +502,9 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
       return wave_end ? edge_row[j] : from_lane;
     };
     pvrtc_encode_strip<EXCHANGE>(1u << sb, load_px, load_colours, store, right_of);
+#if defined(ICAMD_PVRTC_FUSION_PROBE)
+    asm volatile("" :: "v"(pr_acc));
+#endif
   }
   if (!L.stage_stores) return;
   // Write-out: every lane stores 16 bytes (two Z-adjacent blocks) per round; 32 lanes cover one 512-byte run (sb = 3).
