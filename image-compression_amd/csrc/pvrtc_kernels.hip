@@ -366,7 +366,13 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     const uint32_t xl = (bx - 1u) & bw_mask, xr = (bx + 1u) & bw_mask;
 
     // DMA: this wave's ring (all 64 lanes of a wave share the strip row and the image when the region is >= 64 columns wide)
-    lds_u32 *ring = DMA ? (lds_u32 *)(lds_rows + (threadIdx.x >> 6) * (kRowRing * 512u)) : nullptr;
+    // (r04) the wave's index is made a scalar explicitly: the ring slot (M0) is then computed on the scalar unit instead of
+    // two v_readfirstlane + vector adds per pixel row (encode kernel 268.0 -> 264.4 us, profiles/r04_ab_pvrtc_scalar_ring.log).
+    // The same for the strip's row (readfirstlane of by0 * 4 feeding the DMA addresses as an SGPR pair) was tried and is NOT
+    // used: it produced wrong first blocks of strips, deterministically per build, although lane 0's value broadcast through
+    // a VGPR gives exact results -- an issue of the SGPR-operand code path that was not tracked down (same log).
+    const uint32_t wave_s = DMA ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x >> 6;
+    lds_u32 *ring = DMA ? (lds_u32 *)(lds_rows + wave_s * (kRowRing * 512u)) : nullptr;
     const uint32_t ring_lane_byte = DMA ? (uint32_t)(uintptr_t)ring + (threadIdx.x & 63u) * 16u : 0u;
     // pixel row r of the strip -> slot r % kRowRing.  The walk ends at row 4 K (the first row below the strip); the three
     // requests past it keep the wait counts uniform but re-fetch row 4 K (an L2 hit) instead of 3 / 32 more HBM bytes.
