@@ -736,6 +736,11 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
                     "--size", "8192", "--steps", "3"])
     assert d["scaling"] == "strong" and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
     assert d["config"]["world_size"] == 1 and d["slab_block_rows"] == [2048]
+    # two ranks on this box's one GPU over gloo (the gather staged through the host): unequal slabs, batched isend / irecv
+    import torch
+    if torch.cuda.device_count() < 2:
+        d = _run_bench(["--gpus", "2", "--backend", "gloo", "--shard", "slab", "--workload", "dxt1_rgb888", "--size", "2052", "--steps", "3"])
+        assert d["n_gpus"] == 2 and d["slab_block_rows"] == [256, 257] and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
 
 
 def test_rccl_code_path_executes_with_a_single_rank(pkg):
