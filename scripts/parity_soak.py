@@ -117,4 +117,44 @@ for rep in range(max(1, n_seeds // 50)):
                 bad += 1
                 print("MISMATCH etc shortcut set", comps, strategy, h, w)
 print("constructed boundary sets on the device: %d blocks, %d mismatches in total, %.1f s" % (checked, bad, time.time() - t0))
+
+# r04: the palette-plane kernels (decoders, Downsample incl. the batched entry, DXT1 -> ETC1 transcode) on ARBITRARY block words
+# -- DXT1 three-colour mode, equal endpoints, DXT5 six-value alpha, ETC1 differential bases outside 0..31 -- random geometry
+g = np.random.Generator(np.random.PCG64(0xD04))
+words = 0
+for it in range(12 * n_seeds):
+    compressor, fmt, codec, strategy = [(T.DXTC, T.RGB, T.DXT1, 2), (T.DXTC, T.BGR, T.DXT1, 2), (T.DXTC, T.RGBA, T.DXT5, 2),
+                                        (T.DXTC, T.BGRA, T.DXT5, 2), (T.ETC, T.RGB, T.ETC1, 3), (T.ETC, T.RGB, T.ETC1, 0)][it % 6]
+    bb = 16 if codec == T.DXT5 else 8
+    rows, cols, n = 2 * int(g.integers(1, 24)), 2 * int(g.integers(1, 40)), int(g.integers(1, 5))
+    h, w = 4 * rows, 4 * cols
+    raw = g.integers(0, 256, size=(n, rows * cols, bb), dtype=np.uint8)
+    kind = int(g.integers(0, 4))
+    if codec != T.ETC1 and kind == 1:
+        c = raw[:, :, bb - 8:bb - 4]
+        raw[:, :, bb - 8:bb - 4] = np.sort(c.copy().view(np.uint16), axis=2).view(np.uint8)
+    elif codec != T.ETC1 and kind == 2:
+        raw[:, :, bb - 6:bb - 4] = raw[:, :, bb - 8:bb - 6]
+    elif codec == T.DXT5 and kind == 3:
+        raw[:, :, :2] = np.sort(raw[:, :, :2], axis=2)
+    d = torch.from_numpy(raw.reshape(n, -1).copy()).cuda()
+    got = pkg.downsample_device(compressor, fmt, d, h, w, etc_strategy=strategy, n_images=n)
+    swap = fmt in (T.BGR, T.BGRA)
+    dec = pkg.decode_device(codec, d[0].contiguous(), h, w, swap_rb=swap)
+    torch.cuda.synchronize()
+    for i in range(n):
+        words += 1
+        if got[i].cpu().numpy().tobytes() != T.oracle_downsample(compressor, fmt, raw[i].tobytes(), h, w, strategy):
+            bad += 1
+            print("MISMATCH downsample of arbitrary words", codec, fmt, h, w, i, kind)
+    words += 1
+    if dec.cpu().numpy().reshape(-1).tobytes() != np.asarray(T.oracle_decode(codec, raw[0].tobytes(), h, w, swap=int(swap))).tobytes():
+        bad += 1
+        print("MISMATCH decode of arbitrary words", codec, fmt, h, w, kind)
+    if codec == T.DXT1:
+        words += 1
+        if pkg.transcode_dxt1_to_etc1_host(raw[0].tobytes()) != T.oracle_transcode(raw[0].tobytes()):
+            bad += 1
+            print("MISMATCH transcode of arbitrary words", h, w, kind)
+print("arbitrary block words through the palette-plane kernels: %d checks, %d mismatches in total, %.1f s" % (words, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
