@@ -80,6 +80,10 @@ extern "C" {
 // (noise), 0.190 -> 0.183 (flat), 0.174 -> 0.172 (smooth); RGBA8 0.190 -> 0.201 and DXT5 0.253 -> 0.259 got slower
 // (67-71 VGPRs instead of 51-54) and keep one block per lane.
 __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_x2_kernel(GridParams P) { dxt_encode_two<3, false>(P); }
+#if defined(ICAMD_DXT1_RGBA8_X2_SMALL)
+// A/B only (r04, VERDICT r03 item 6: "fewer, fatter workgroups for <= 64 MiB launches so that a launch is one residency round")
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_x2_kernel(GridParams P) { dxt_encode_two<4, false>(P); }
+#endif
 
 // *_kernel: 256 x 1-block tiles (block grids more than 128 columns wide); *_narrow_kernel: any tile shape
 __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_kernel(GridParams P) { dxt_encode_one<4, false, true>(P); }
@@ -100,6 +104,10 @@ hipError_t launch_dxt(int codec, int comps, const GridParams &P, hipStream_t str
     if (comps != 4) return hipErrorInvalidValue;
     return launch_tiled(icamd_dxt5_rgba8_kernel, icamd_dxt5_rgba8_narrow_kernel, P, stream);
   }
+#if defined(ICAMD_DXT1_RGBA8_X2_SMALL)
+  if (comps == 4 && (uint64_t)P.n_images * P.block_rows * P.block_cols <= (1ull << 20))  // one 4096^2 image or less
+    return launch_tiled(icamd_dxt1_rgba8_x2_kernel, icamd_dxt1_rgba8_narrow_kernel, P, stream, 8, 2);
+#endif
   if (comps == 4) return launch_tiled(icamd_dxt1_rgba8_kernel, icamd_dxt1_rgba8_narrow_kernel, P, stream);
   return launch_tiled(icamd_dxt1_rgb888_x2_kernel, icamd_dxt1_rgb888_narrow_kernel, P, stream, 8, 2);
 }
