@@ -81,7 +81,9 @@ extern "C" {
 // (67-71 VGPRs instead of 51-54) and keep one block per lane.
 __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgb888_x2_kernel(GridParams P) { dxt_encode_two<3, false>(P); }
 #if defined(ICAMD_DXT1_RGBA8_X2_SMALL)
-// A/B only (r04, VERDICT r03 item 6: "fewer, fatter workgroups for <= 64 MiB launches so that a launch is one residency round")
+// A/B only (r04, VERDICT r03 item 6: "fewer, fatter workgroups for <= 64 MiB launches so that a launch is one residency round"):
+// one 4096^2 image per call 16.0 -> 17.1 us with an event pair, 13.9 -> 15.2 us back to back -- slower, not shipped
+// (profiles/r04_single_image_timeline.txt, section c)
 __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_rgba8_x2_kernel(GridParams P) { dxt_encode_two<4, false>(P); }
 #endif
 
