@@ -10,13 +10,14 @@ namespace {
 constexpr int kWords(int codec) { return codec == ICAMD_DXT5 ? 4 : 2; }
 }
 
+// (r, c) of output block k: the source block it copies / replicates, and whether it is a pad block.
 template <int CODEC, int STRATEGY>
-__device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
+__device__ __forceinline__ void pad_block(const BlockOpParams &P, uint32_t r, uint32_t c, bool copy_interior, bool make_border) {
   constexpr int W = kWords(CODEC);
-  const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
   const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src);
-  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + (size_t)k * W;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + ((size_t)r * P.out_cols + c) * W;
   const bool in_rows = r < P.in_rows, in_cols = c < P.in_cols;
+  if (in_rows && in_cols ? !copy_interior : !make_border) return;
   const uint32_t sr = in_rows ? r : P.in_rows - 1, sc = in_cols ? c : P.in_cols - 1;
   const uint32_t *s = src + ((size_t)sr * P.in_cols + sc) * W;
   uint32_t w[4];
@@ -42,6 +43,25 @@ __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
     dst[2] = w[2];
     dst[3] = dxt_pad_color_bits(w[3], kind);
   }
+}
+
+// DXT: one pass over the output grid (a pad block is a few bit edits).  ETC1 (r04): a pad block is a decode + re-encode -- up to
+// the whole kSmallerError search -- so the copy of the image's own blocks runs as one light kernel over the grid (PART 1: 7 VGPRs,
+// 8 waves per SIMD) and the pad blocks as a second, small launch over the BORDER only (PART 2: the in_rows x extra columns to
+// the right, then the extra rows over the full width); in one kernel the searches' 121 VGPRs capped the copy at 4 waves per SIMD
+// and every wave that touched the border ran the search (28.6 -> ~7 us per 4096^2 image padded by 8 pixels).
+template <int CODEC, int STRATEGY, int PART>
+__device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
+  if (PART == 2) {
+    const uint32_t dc = P.out_cols - P.in_cols, right = P.in_rows * dc;
+    uint32_t r, c;
+    if (k < right) { r = k / dc; c = P.in_cols + (k - r * dc); }
+    else { const uint32_t j = k - right; r = P.in_rows + j / P.out_cols; c = j - (r - P.in_rows) * P.out_cols; }
+    pad_block<CODEC, STRATEGY>(P, r, c, false, true);
+    return;
+  }
+  const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
+  pad_block<CODEC, STRATEGY>(P, r, c, true, PART == 0);
 }
 
 // STRATEGY: the ETC1 re-encode strategy as a compile-time constant (one kernel per strategy, like the encoders: the
@@ -126,10 +146,10 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
   else store_stream8(dst, out[0], out[1]);
 }
 
-#define ICAMD_PAD_KERNEL(NAME, CODEC, STRATEGY)                                                                \
+#define ICAMD_PAD_KERNEL(NAME, CODEC, STRATEGY, PART)                                                          \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pad_##NAME##_kernel(BlockOpParams P) { \
     const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
-    if (k < P.total_out) pad_one<CODEC, STRATEGY>(P, k);                                                       \
+    if (k < P.total_out) pad_one<CODEC, STRATEGY, PART>(P, k);                                                 \
   }
 #define ICAMD_DOWNSAMPLE_KERNEL(NAME, CODEC, STRATEGY)                                                         \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup)                                           \
@@ -141,12 +161,13 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
     if (k < P.total_out) downsample_one<CODEC, STRATEGY>(P, k, stash);                                         \
   }
 
-ICAMD_PAD_KERNEL(dxt1, ICAMD_DXT1, 0)
-ICAMD_PAD_KERNEL(dxt5, ICAMD_DXT5, 0)
-ICAMD_PAD_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
-ICAMD_PAD_KERNEL(etc1_split_v, ICAMD_ETC1, 1)
-ICAMD_PAD_KERNEL(etc1, ICAMD_ETC1, 2)
-ICAMD_PAD_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
+ICAMD_PAD_KERNEL(dxt1, ICAMD_DXT1, 0, 0)
+ICAMD_PAD_KERNEL(dxt5, ICAMD_DXT5, 0, 0)
+ICAMD_PAD_KERNEL(etc1_copy, ICAMD_ETC1, 0, 1)
+ICAMD_PAD_KERNEL(etc1_border_split_h, ICAMD_ETC1, 0, 2)
+ICAMD_PAD_KERNEL(etc1_border_split_v, ICAMD_ETC1, 1, 2)
+ICAMD_PAD_KERNEL(etc1_border, ICAMD_ETC1, 2, 2)
+ICAMD_PAD_KERNEL(etc1_border_heuristic, ICAMD_ETC1, 3, 2)
 ICAMD_DOWNSAMPLE_KERNEL(dxt1, ICAMD_DXT1, 0)
 ICAMD_DOWNSAMPLE_KERNEL(dxt5, ICAMD_DXT5, 0)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
@@ -169,10 +190,17 @@ hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_pad_dxt1_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_pad_dxt5_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_ETC1) {
-    if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_split_h_kernel, grid, block, 0, stream, P);
-    else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_pad_etc1_split_v_kernel, grid, block, 0, stream, P);
-    else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_pad_etc1_heuristic_kernel, grid, block, 0, stream, P);
-    else hipLaunchKernelGGL(icamd_pad_etc1_kernel, grid, block, 0, stream, P);
+    hipLaunchKernelGGL(icamd_pad_etc1_copy_kernel, grid, block, 0, stream, P);
+    BlockOpParams B = P;  // the pad blocks only: right of the image, then below it
+    const uint64_t border = (uint64_t)P.in_rows * (P.out_cols - P.in_cols) + (uint64_t)(P.out_rows - P.in_rows) * P.out_cols;
+    B.total_out = (uint32_t)border;
+    if (border) {
+      const dim3 bgrid((B.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup);
+      if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_h_kernel, bgrid, block, 0, stream, B);
+      else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_v_kernel, bgrid, block, 0, stream, B);
+      else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_pad_etc1_border_heuristic_kernel, bgrid, block, 0, stream, B);
+      else hipLaunchKernelGGL(icamd_pad_etc1_border_kernel, bgrid, block, 0, stream, B);
+    }
   } else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -59,6 +59,38 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         t = timeit(down_b, 10)
         print("downsample %-5s batched%s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one launch)" % (
             name, " strategy %d" % strat if codec == 2 else "", px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
+    # Pad (helper.h:393-477) to a grid two block rows / columns larger: a copy plus one re-encoded / bit-edited border
+    ph = pw = n + 8
+    pout = torch.empty((batch, ((ph + 3) // 4) * ((pw + 3) // 4) * bb), dtype=torch.uint8, device=dev)
+    def pad():
+        for i in range(batch):
+            rc = L.icamd_pad_device(compressor, 2, fmt, n, n, ctypes.c_void_p(blocks[i].data_ptr()), ph, pw,
+                                    ctypes.c_void_p(pout[i].data_ptr()), pout.shape[1], sh)
+            assert rc == 0
+    t = timeit(pad, 5)
+    print("pad %-5s to %d^2 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)" % (
+        name, ph, px / t / 1e6, (blocks.numel() + pout.numel()) / t / 1e9, t * 1e3, batch))
+    sub = torch.empty((batch, per_in // 4), dtype=torch.uint8, device=dev)
+    def subimage():
+        for i in range(batch):
+            rc = L.icamd_copy_subimage_device(compressor, fmt, n, n, ctypes.c_void_p(blocks[i].data_ptr()), n // 4, n // 4, n // 2, n // 2,
+                                              ctypes.c_void_p(sub[i].data_ptr()), sub.shape[1], sh)
+            assert rc == 0
+    t = timeit(subimage, 5)
+    print("copy_subimage %-5s %d^2 of %d^2  %6.0f GB/s (%.3f ms per %d images, one call per image)" % (
+        name, n // 2, n, 2 * sub.numel() / t / 1e9, t * 1e3, batch))
+    colour = (ctypes.c_uint8 * 4)(200, 100, 50, 255)
+    def solid():
+        for i in range(batch):
+            rc = L.icamd_create_solid_device(compressor, fmt, n, n, colour, ctypes.c_void_p(blocks[i].data_ptr()), per_in, sh)
+            assert rc == 0
+    if codec == 2:
+        keep = blocks.clone()
+    t = timeit(solid, 5) if codec == 2 else None  # (overwrites `blocks`: last use of the ETC1 grid; restored below)
+    if t:
+        print("create_solid %-5s %6.0f GB/s written (%.3f ms per %d images of %d^2, one call per image)" % (name, blocks.numel() / t / 1e9, t * 1e3, batch, n))
+        blocks.copy_(keep); del keep
+    del pout, sub
     if codec == 0:
         work = blocks.clone()
         def tr():
