@@ -37,7 +37,7 @@ EXPORTS = [
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
     "icamd_downsample", "icamd_downsample_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
-    "icamd_pvrtc2_set_workspace", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
+    "icamd_pvrtc2_set_workspace", "icamd_pvrtc2_tune", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
     "icamd_container_size", "icamd_container_write",
@@ -108,6 +108,9 @@ def lib():
             L.icamd_pvrtc2_workspace_size.argtypes = [_u32, _u32]
             L.icamd_pvrtc2_set_workspace.restype = _ci
             L.icamd_pvrtc2_set_workspace.argtypes = [_vp, _sz]
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_tune"):
+            L.icamd_pvrtc2_tune.restype = _ci
+            L.icamd_pvrtc2_tune.argtypes = [_ci, _ci]
             L.icamd_host_register.restype = _ci
             L.icamd_host_register.argtypes = [_vp, _sz]
             L.icamd_host_unregister.restype = _ci
@@ -334,6 +337,12 @@ def pvrtc_decompress_host(blocks, size):
 
 def pvrtc_workspace_size(size, n_images=1):
     return lib().icamd_pvrtc2_workspace_size(size, n_images)
+
+
+def pvrtc_tune(mode=0, log2_strip=-1):
+    """icamd_pvrtc2_tune (extension, test / tuning hook): 0 = automatic, 1 = always morph + encode, 2 = the one-pass kernel
+    wherever it is eligible; log2_strip < 0 = automatic strip height.  Process-wide; results are identical either way."""
+    return _check(lib().icamd_pvrtc2_tune(int(mode), int(log2_strip)), "icamd_pvrtc2_tune")
 
 
 def pvrtc_set_workspace(workspace):

@@ -376,6 +376,12 @@ int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
   return ICAMD_OK;
 }
 
+int icamd_pvrtc2_tune(int mode, int log2_strip) {
+  if (mode < 0 || mode > 2) return fail(ICAMD_ERR_ARG, "icamd_pvrtc2_tune: mode must be 0 (auto), 1 (two kernels) or 2 (one pass)");
+  icamd::pvrtc2_tune(mode, log2_strip);
+  return ICAMD_OK;
+}
+
 int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
                                   uint32_t height, uint32_t width,
                                   uint32_t padded_height, uint32_t padded_width,

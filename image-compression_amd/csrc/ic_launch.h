@@ -78,6 +78,9 @@ size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images);
 void pvrtc2_set_workspace(void *d_workspace, size_t bytes);
 // this thread's library-owned workspace slot (0 / 1) for the PVRTC launches that follow: one per alternating stream
 void pvrtc2_select_workspace(int slot);
+// which kernels whole-texture PVRTC launches take: mode 0 = automatic, 1 = always morph + encode, 2 = the one-pass kernel
+// wherever it is eligible (512^2 ... 4096^2); log2_strip < 0 = automatic strip height of the one-pass kernel
+void pvrtc2_tune(int mode, int log2_strip);
 
 struct DecodeParams {
   const uint8_t *blocks;

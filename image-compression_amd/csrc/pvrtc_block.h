@@ -238,6 +238,36 @@ static_assert(blend53_is_nested_average(), "(5a+3b)/8 != avg(a, avg(b, avg(a,b))
 // colours (5A+3B)/8 and (3A+5B)/8 (pvrtc.cc:111-135) are nested byte averages (v_lerp_u8, all four channels per
 // instruction), the four L1 distances are v_sad_u8.  The value (0..3) is ADDED into `acc` at the byte whose unit
 // is `unit` (1, 1<<8, ...).  Same decisions as best_modulation().
+#if !defined(ICAMD_HOST_EMULATION) && !defined(ICAMD_PVRTC_NO_SCAN_SDWA)
+// The early-exit scan  s1 + (s1 && s2) + (s1 && s2 && s3)  as nested selects  e1 ? (e2 ? (e3 ? 3 : 2) : 1) : 0  on VCC, the
+// last select writing byte J of `acc` in place (SDWA dst_sel, the other bytes preserved): 3 v_cmp + 3 v_cndmask and no scalar
+// instruction, where the plain expression compiles to 3 v_cmp + 2 s_and_b64 + 2 v_cndmask + v_addc + v_lshl_add (r05: -2 %
+// on the one-pass kernel, profiles/r05_ab_pvrtc_onepass.log; -DICAMD_PVRTC_NO_SCAN_SDWA builds the plain form).  The byte of
+// `acc` that `unit` addresses must be zero on entry.
+ICAMD_DEV uint32_t scan_into_byte(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t unit, uint32_t acc) {
+  uint32_t x;
+  const uint32_t three = 3u, zero = 0u;
+#define ICAMD_SCAN_HEAD                                                                                                   \
+  "v_cmp_lt_u32_e32 vcc, %[d3], %[d2]\n\tv_cndmask_b32_e32 %[x], 2, %[three], vcc\n\t"                                   \
+  "v_cmp_lt_u32_e32 vcc, %[d2], %[d1]\n\tv_cndmask_b32_e32 %[x], 1, %[x], vcc\n\tv_cmp_lt_u32_e32 vcc, %[d1], %[d0]\n\t"
+#define ICAMD_SCAN_TAIL(B)                                                                                                \
+  "v_cndmask_b32_sdwa %[acc], %[zero], %[x], vcc dst_sel:" B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+#define ICAMD_SCAN_OPS : [acc] "+v"(acc), [x] "=&v"(x) : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [three] "v"(three), [zero] "v"(zero) : "vcc"
+  if (unit == 1u) asm(ICAMD_SCAN_HEAD "v_cndmask_b32_e32 %[acc], 0, %[x], vcc" ICAMD_SCAN_OPS);  // acc == 0: the whole dword
+  else if (unit == 1u << 8) asm(ICAMD_SCAN_HEAD ICAMD_SCAN_TAIL("BYTE_1") ICAMD_SCAN_OPS);
+  else if (unit == 1u << 16) asm(ICAMD_SCAN_HEAD ICAMD_SCAN_TAIL("BYTE_2") ICAMD_SCAN_OPS);
+  else asm(ICAMD_SCAN_HEAD ICAMD_SCAN_TAIL("BYTE_3") ICAMD_SCAN_OPS);
+#undef ICAMD_SCAN_HEAD
+#undef ICAMD_SCAN_TAIL
+#undef ICAMD_SCAN_OPS
+  return acc;
+}
+#else
+ICAMD_DEV uint32_t scan_into_byte(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t unit, uint32_t acc) {
+  const bool s1 = d1 < d0, s2 = s1 && d2 < d1, s3 = s2 && d3 < d2;  // stop at the first non-improving step
+  return acc + ((uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3) * unit;
+}
+#endif
 ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t unit, uint32_t acc) {
   const uint32_t kSel = 0x07030501u;  // bytes: lo.b1, hi.b1, lo.b3, hi.b3  = R, G, B, A
   const uint32_t c0 = perm(P[1], P[0], kSel), c3 = perm(P[3], P[2], kSel);
@@ -245,8 +275,7 @@ ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t 
   const uint32_t c1 = avg_u8(c0, avg_u8(c3, m)), c2 = avg_u8(c3, avg_u8(c0, m));
   const uint32_t d0 = sad_u8(pixel, c0, 0u), d1 = sad_u8(pixel, c1, 0u);
   const uint32_t d2 = sad_u8(pixel, c2, 0u), d3 = sad_u8(pixel, c3, 0u);
-  const bool s1 = d1 < d0, s2 = s1 && d2 < d1, s3 = s2 && d3 < d2;  // stop at the first non-improving step
-  return acc + ((uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3) * unit;
+  return scan_into_byte(d0, d1, d2, d3, unit, acc);
 }
 
 // The 8 modulation values of one pixel row of a block (bytes of row[0..1], x order), and optionally the value of
@@ -655,6 +684,203 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
   }
 }
 
+// ---- one-pass form (r05): the lane that encodes a block column also MORPHS it ----------------------------------------
+// GetExtremesFast (pvrtc.cc:255-329) consumed one pixel row at a time: the same keys as pvrtc_extremes, the block's four
+// rows arriving in four calls (Q = row inside the block, compile-time), the ten data-dependent pixel look-ups of the final
+// scan batched into one call of `lookup10` (on the device: ten ds_read_b32 from the pixel-row ring under one wait).
+struct PvrtcMorphKeys {
+  uint32_t min_l, max_l, min_rb, max_rb, min_ga, max_ga;
+};
+ICAMD_DEV void pvrtc_keys_reset(PvrtcMorphKeys &k) {
+  k.min_l = k.min_rb = k.min_ga = 0xffffffffu;
+  k.max_l = k.max_rb = k.max_ga = 0u;
+}
+template <int Q>
+ICAMD_DEV void pvrtc_keys_row(PvrtcMorphKeys &k, const uint32_t px[8]) {
+  ICAMD_UNROLL
+  for (int x = 0; x < 8; x += 2) {
+    uint32_t kl[2];
+    ICAMD_UNROLL
+    for (int q = 0; q < 2; ++q) {
+      const int p = 8 * Q + x + q;
+      const uint32_t c = px[x + q], i = (uint32_t)(p & 3);
+      const uint32_t idx4 = (uint32_t)(p & ~3) * 0x01010101u + 0x03020100u;
+      const uint32_t up = (uint32_t)(31 - 2 * p) * 0x00010001u;
+      kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
+      const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16);
+      const uint32_t k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
+      k.min_rb = pk_min_u16(k.min_rb, k_rb);
+      k.min_ga = pk_min_u16(k.min_ga, k_ga);
+      k.max_rb = pk_max_u16(k.max_rb, k_rb + up);
+      k.max_ga = pk_max_u16(k.max_ga, k_ga + up);
+    }
+    const int p = 8 * Q + x;
+    k.min_l = umin3(k.min_l, kl[0], kl[1]);
+    k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(31 - 2 * p), kl[1] + (uint32_t)(31 - 2 * (p + 1)));
+  }
+  k.min_l = opaque(k.min_l); k.max_l = opaque(k.max_l);
+  k.min_rb = opaque(k.min_rb); k.max_rb = opaque(k.max_rb);
+  k.min_ga = opaque(k.min_ga); k.max_ga = opaque(k.max_ga);
+  ICAMD_SCHED_FENCE();
+}
+// lookup10(idx[10], out[10]): out[i] = pixel idx[i] (0..31, raster inside the block) of the block whose rows were just consumed
+template <typename Lookup10>
+ICAMD_DEV void pvrtc_keys_finish(const PvrtcMorphKeys &k, uint32_t image0, Lookup10 &lookup10, uint32_t &col_a, uint32_t &col_b) {
+  const uint32_t kmin[5] = { k.min_l, k.min_rb & 0xffffu, k.min_ga & 0xffffu, k.min_rb >> 16, k.min_ga >> 16 };
+  const uint32_t kmax[5] = { k.max_l, k.max_rb & 0xffffu, k.max_ga & 0xffffu, k.max_rb >> 16, k.max_ga >> 16 };
+  uint32_t idx[10], v[10];
+  ICAMD_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    idx[2 * i] = kmin[i] & 31u;
+    idx[2 * i + 1] = 31u - (kmax[i] & 31u);
+  }
+  lookup10(idx, v);
+  uint32_t best_diff = 0, best_lo = 0, best_hi = 0;
+  ICAMD_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    const uint32_t lo = v[2 * i];
+    const uint32_t hi = (kmax[i] >> 8) == 0u ? image0 : v[2 * i + 1];  // never-updated max -> image pixel 0 (pvrtc.cc:268-269)
+    const uint32_t d = sad_u8(lo, hi, 0u);
+    const bool better = (i == 0) || d > best_diff;
+    best_lo = better ? lo : best_lo;
+    best_hi = better ? hi : best_hi;
+    best_diff = better ? d : best_diff;
+  }
+  const uint32_t s_lo = udot4(best_lo, 0x01010101u, 0u), s_hi = udot4(best_hi, 0x01010101u, 0u);
+  const bool swap = s_hi < s_lo;
+  col_a = swap ? best_hi : best_lo;
+  col_b = swap ? best_lo : best_hi;
+}
+
+// One lane = one block column of a strip of K blocks (block rows 0 .. K-1 of the strip), walking pixel rows -4 .. 4 K + 3:
+// every row is consumed twice from the same row ring -- by the morph when it arrives (row m) and by the modulation five
+// rows later (row e = m - 5): rows 2, 3 of block s-1 and rows 0, 1 of block s interpolate between colour rows s-1 and s
+// (pvrtc.cc:216-227), so block s must be morphed (its last row is 4 s + 3) before row 4 s - 2 is modulated.  A "tick"
+// hands over both rows.  Per SEGMENT s = -1 .. K+1 (four ticks):
+//   tick(4 s + 3):  last row of block s -> its two colours;  exchange(): the colours of the block columns left and right
+//                   (neighbour lanes; on the device wave-edge lanes go through LDS, which is where the workgroup's one
+//                   barrier per segment sits) and, riding on the same barrier, the column-0 modulation values of the block
+//                   right of block s-2 -- which is why a block is finished one segment late (block j in segment j+2):
+//                   its last term  sum_y |m(7, y) - m(8, y)|  (pvrtc.cc:426-429) needs the right-hand lane's values;
+//   rows 4 s - 2, 4 s - 1 (block s-1 rows 2, 3), 4 s (block s row 0, closes block s-1's vertical differences), 4 s + 1.
+// tick(m, mp, ep):       pixel rows m (morph) and m - 5 (modulation) of the strip; wrap and clamping are the caller's.
+// lookup10(idx, out):    see pvrtc_keys_finish; refers to the block whose last row the latest tick delivered.
+// exchange(s, own, col0, left, right, right_col0): own = colours of block row s of this column, col0 = this lane's column-0
+//                        values of block s-2; returns the colours left / right of `own` and the column-0 values of the block
+//                        right of block s-2.
+// store(j, data, one_bpp, own): block j of the strip is finished.
+// K must be >= 1; segments -1 and K+1 only morph / only finish.
+template <typename Tick, typename Lookup10, typename Exchange, typename BlockStore>
+ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tick, Lookup10 &lookup10, Exchange &exchange,
+                                   BlockStore &store) {
+  const int K = (int)k_blocks;
+  PvrtcMorphKeys keys;
+  pvrtc_keys_reset(keys);
+  uint32_t mp[8], ep[8];
+  uint32_t A[3][4];  // colour row s-1 as channel pairs
+  ICAMD_UNROLL
+  for (int c = 0; c < 3; ++c)
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) A[c][v] = 0u;
+  PvrtcBlockAcc acc = { 0, 0, 0, 0, 0, 0, 0, 0 }, def = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  PvrtcColors own_acc = { 0u, 0u }, own_def = { 0u, 0u };
+  uint32_t prev[2] = { 0u, 0u };
+  tick(-4, mp, ep); pvrtc_keys_row<0>(keys, mp);
+  tick(-3, mp, ep); pvrtc_keys_row<1>(keys, mp);
+  tick(-2, mp, ep); pvrtc_keys_row<2>(keys, mp);
+  PvrtcColors cc[3] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+  ICAMD_NOUNROLL
+  for (int s = -1;; ++s) {
+    if (s <= K) {
+      tick(4 * s + 3, mp, ep);
+      pvrtc_keys_row<3>(keys, mp);
+      uint32_t a, c;
+      pvrtc_keys_finish(keys, image0, lookup10, a, c);
+      cc[1].a = channel_reduce(a, false);
+      cc[1].b = channel_reduce(c, true);
+      pvrtc_keys_reset(keys);
+    }
+    uint32_t right_col0 = 0u;
+    exchange(s, cc[1], def.col0, cc[0], cc[2], right_col0);
+    if (s >= 2) {
+      def.vc = sad_u8(def.col7, right_col0, def.vc);  // sum_y |m(7, y) - m(8, y)|
+      bool one_bpp;
+      const uint32_t data = pvrtc_acc_finish(def, &one_bpp);
+      store((uint32_t)(s - 2), data, one_bpp, own_def);
+    }
+    if (s > K) break;
+    // colour rows (s-1, s): V = 32 A, dV = 8 (B - A) -- see pvrtc_encode_strip
+    uint32_t V[3][4], dV[3][4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t b[4] = { pair_rb(cc[c].a), pair_ga(cc[c].a), pair_rb(cc[c].b), pair_ga(cc[c].b) };
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        V[c][v] = A[c][v] << 5;
+        dV[c][v] = (b[v] - A[c][v]) << 3;
+        A[c][v] = b[v];
+      }
+    }
+    uint32_t row[2];
+    if (s >= 1) {  // row 2 of block s-1, weight 0
+      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);  // "horizontal_count" = sum |m - m(x, y+1)| (pvrtc.cc:426-429)
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row<true>(acc, 2, row, 0u);
+      prev[0] = row[0]; prev[1] = row[1];
+    }
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_SCHED_FENCE();
+    tick(4 * s + 4, mp, ep);
+    pvrtc_keys_row<0>(keys, mp);
+    if (s >= 1) {  // row 3 of block s-1, weight 1
+      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row<true>(acc, 3, row, 0u);
+      prev[0] = row[0]; prev[1] = row[1];
+    }
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_SCHED_FENCE();
+    tick(4 * s + 5, mp, ep);
+    pvrtc_keys_row<1>(keys, mp);
+    if (s >= 0) {  // row 0 of block s, weight 2 -- for s == K the row below the strip, which only completes block K-1
+      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      if (s >= 1) {
+        acc.hc = sad_u8(prev[0], row[0], acc.hc);
+        acc.hc = sad_u8(prev[1], row[1], acc.hc);
+        def = acc;  // complete but for the right-hand column: finished in the next segment
+        own_def = own_acc;
+      }
+      own_acc = cc[1];
+      acc.hc = acc.vc = acc.d1 = acc.d2 = 0u;
+      pvrtc_acc_row<true>(acc, 0, row, 0u);
+      prev[0] = row[0]; prev[1] = row[1];
+    }
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_SCHED_FENCE();
+    tick(4 * s + 6, mp, ep);
+    pvrtc_keys_row<2>(keys, mp);
+    if (s >= 0 && s < K) {  // row 1 of block s, weight 3
+      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      acc.hc = sad_u8(prev[0], row[0], acc.hc);
+      acc.hc = sad_u8(prev[1], row[1], acc.hc);
+      pvrtc_acc_row<true>(acc, 1, row, 0u);
+      prev[0] = row[0]; prev[1] = row[1];
+    }
+    ICAMD_SCHED_FENCE();
+  }
+}
+
 // FromZOrder inverse (pvrtc.cc:80-86): x occupies the odd bits, y the even bits of the block index.
 ICAMD_DEV uint32_t spread_bits16(uint32_t v) {
   v = (v | v << 8) & 0x00ff00ffu;
@@ -805,6 +1031,46 @@ static inline int emul_pvrtc2(const uint8_t *src, uint32_t n, uint8_t *out) {
         };
         pvrtc_encode_strip<true>(k_blocks, load_px, load_colours, store, right_of);
         if (!ok) return 0;
+        // the one-pass walker (r05: what icamd_pvrtc2_onepass_kernel runs): morphs its own column, is handed the neighbour
+        // columns' colours and column-0 values (here: the reference values; what it hands out is checked against them)
+        int last_m = -100;
+        auto tick = [&](int m, uint32_t *mp, uint32_t *ep) {
+          last_m = m;
+          const uint32_t ym = (by0 * 4 + (uint32_t)m) & (n - 1), ye = (by0 * 4 + (uint32_t)(m - 5)) & (n - 1);
+          for (int x = 0; x < 8; ++x) {
+            mp[x] = img[(size_t)ym * n + bx * 8 + x];
+            ep[x] = img[(size_t)ye * n + bx * 8 + x];
+          }
+        };
+        auto lookup10 = [&](const uint32_t idx[10], uint32_t v[10]) {
+          const uint32_t y0 = (by0 * 4 + (uint32_t)(last_m - 3)) & (n - 1);  // first row of the block just consumed
+          for (int i = 0; i < 10; ++i) v[i] = img[(size_t)(y0 + idx[i] / 8) * n + bx * 8 + idx[i] % 8];
+        };
+        auto exchange = [&](int s, const PvrtcColors &own, uint32_t col0, PvrtcColors &left, PvrtcColors &right, uint32_t &right_col0) {
+          if (s <= (int)k_blocks) {
+            const uint32_t yy = (by0 + bh + (uint32_t)s) % bh;
+            const size_t o2 = (size_t)yy * bw;
+            if (own.a != ca[o2 + bx] || own.b != cb[o2 + bx]) ok = 0;
+            left.a = ca[o2 + (bx + bw - 1) % bw]; left.b = cb[o2 + (bx + bw - 1) % bw];
+            right.a = ca[o2 + (bx + 1) % bw]; right.b = cb[o2 + (bx + 1) % bw];
+          }
+          if (s >= 2) {
+            uint32_t own0 = 0, r = 0;
+            for (int y = 0; y < 4; ++y) {
+              own0 |= (uint32_t)mods[(size_t)((by0 + (uint32_t)s - 2) * 4 + y) * n + bx * 8] << (8 * y);
+              r |= (uint32_t)mods[(size_t)((by0 + (uint32_t)s - 2) * 4 + y) * n + ((bx * 8 + 8) & (n - 1))] << (8 * y);
+            }
+            if (own0 != col0) ok = 0;
+            right_col0 = r;
+          }
+        };
+        uint32_t stored = 0;
+        auto store1 = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
+          store(j, data, one_bpp, own);
+          stored |= 1u << j;
+        };
+        pvrtc_onepass_strip(k_blocks, img[0], tick, lookup10, exchange, store1);
+        if (!ok || stored != (k_blocks >= 32 ? 0xffffffffu : (1u << k_blocks) - 1u)) return 0;
       }
   delete[] ab; delete[] ca; delete[] cb; delete[] mods; delete[] self_right; delete[] self_below;
   return 1;

@@ -24,6 +24,9 @@
 // per lane (+37 % modulation work) removes every dependency between lanes.
 // Launch order is morph(all images of a group) then encode(same group), groups as large as the workspace allows
 // (see launch_pvrtc2); toroidal wrap (pvrtc.cc:216-227,416-423) is applied to block / pixel coordinates.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -556,7 +559,149 @@ extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc2_encode_n
   pvrtc2_encode<false>(L, blockIdx.x, lds, nullptr);
 }
 
-const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_encode_kernel"; }
+// ---- one-pass kernel (r05) ---------------------------------------------------------------------------------------------
+// ONE read of the pixels, no workspace: the lane that encodes a block column also morphs it (pvrtc_onepass_strip).
+//   * a workgroup is one WHOLE block row of the image wide (bw = 64 ... 512 lanes, 1 ... 8 waves: textures of 512^2 ... 4096^2)
+//     and K = 4 ... 64 blocks tall: the toroidal wrap (pvrtc.cc:216-227) stays inside the workgroup, so NO block column is
+//     morphed twice; vertically a strip morphs K + 2 block rows for K encoded (K = 32: + 6 % of the morph, which is a third
+//     of the work);
+//   * pixel rows arrive by LDS-DMA in a per-wave ring of 8 rows (16 KiB): row m is morphed when it lands and modulated five
+//     rows later from the same slot, which row m + 3 then takes -- three rows (6 KiB per wave) in flight, waits counted by
+//     hand (every tick issues exactly one row and waits with vmcnt(4); stores only make that wait stricter);
+//   * a block's colours go to the neighbour lanes by DPP wave shifts; the two edge lanes of every wave go through 32 bytes
+//     of LDS per wave and parity and ONE s_barrier per block row, which also carries the column-0 modulation values the
+//     last lane of a wave needs from the first lane of the next (the reason blocks are finished one segment late);
+//   * finished blocks are parked in a per-wave LDS tile (4 block rows x 64 columns, Z order) and leave as 128-byte runs.
+// LDS: waves x (16 KiB ring + 2.25 KiB tile) + 64 B x waves = 150 KiB for 8 waves: one workgroup per CU, 2 waves per SIMD,
+// which is what the ~200 VGPRs of the fused walk allow anyway.  Everything that touches LDS or memory inside the walk is
+// inline asm or a DMA builtin: hipcc drains the ring (vmcnt(0)) in front of any LDS access it can see.
+typedef uint32_t icamd_u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOnePassRing = 8;
+constexpr uint32_t kOnePassChunkSlots = 18;                                  // 4 x 4 blocks in Z order + 2 (16-byte aligned stride)
+constexpr uint32_t kOnePassWaveDwords = kOnePassRing * 512u + 16u * kOnePassChunkSlots * 2u;  // ring + tile: 18 688 bytes
+constexpr uint32_t kOnePassXchDwords = 8;                                    // per wave and parity: [lo.a lo.b col0 - | hi.a hi.b - -]
+
+__device__ __forceinline__ uint32_t dpp_from_lower_lane(uint32_t v) {  // lane i <- lane i - 1 (wave_shr:1); lane 0 keeps v
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {  // lane i <- lane i + 1 (wave_shl:1); lane 63 keeps v
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+}
+
+extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(PvrtcLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = L.size, log2_n = L.log2_bw + 3u;
+  const uint32_t sb = L.log2_strip, K = 1u << sb;
+  const uint32_t log2_spi = L.log2_bw + 1u - sb;  // strips per image = (size / 4) >> sb
+  const uint32_t image = blockIdx.x >> log2_spi, by0 = (blockIdx.x & ((1u << log2_spi) - 1u)) << sb;
+  const uint32_t bx = threadIdx.x, lane = threadIdx.x & 63u;
+  const uint32_t W = blockDim.x >> 6;
+  const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+  uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
+  const uint32_t image0 = opaque(img[0]);  // pvrtc.cc:268-269: never-updated maxima refer to IMAGE pixel 0
+
+  lds_u32 *ring = (lds_u32 *)(lds_dyn + wave_s * kOnePassWaveDwords);
+  const uint32_t ring_lane_byte = (uint32_t)(uintptr_t)ring + lane * 16u;
+  const uint32_t tile_byte = (uint32_t)(uintptr_t)ring + kOnePassRing * 2048u;
+  const uint32_t xch_byte = (uint32_t)(uintptr_t)(lds_u32 *)(lds_dyn + W * kOnePassWaveDwords);
+
+  // pixel row m of the strip (-4 ... 4 K + 3; requests past the end re-fetch the last row so that the wait counts stay
+  // uniform) -> ring slot m mod 8, [half][lane][4 pixels]
+  const int last_row = (int)(4u * K + 3u);
+  auto dma_row = [&](int m) {
+    const uint32_t y = (by0 * 4u + (uint32_t)(m < last_row ? m : last_row)) & (n - 1u);
+    const uint32_t *q = img + ((y << log2_n) + bx * 8u);
+    lds_u32 *slot = ring + ((uint32_t)m & (kOnePassRing - 1u)) * 512u;
+    __builtin_amdgcn_global_load_lds(q, slot, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(q + 4, slot + 256, 16, 0, 0);
+  };
+  dma_row(-4); dma_row(-3); dma_row(-2);
+  int cur_m = -4;
+  auto tick = [&](int m, uint32_t *mp, uint32_t *ep) {
+    cur_m = m;
+    // rows m + 1 and m + 2 (four DMA instructions) may still be in flight; row m and everything older has landed
+    const uint32_t addr_m = ring_lane_byte + ((uint32_t)m & 7u) * 2048u, addr_e = ring_lane_byte + ((uint32_t)(m + 3) & 7u) * 2048u;
+    uint4 m0, m1, e0, e1;
+    asm volatile("s_waitcnt vmcnt(4)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                 "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(m0), "=&v"(m1), "=&v"(e0), "=&v"(e1) : "v"(addr_m), "v"(addr_e) : "memory");
+    mp[0] = m0.x; mp[1] = m0.y; mp[2] = m0.z; mp[3] = m0.w; mp[4] = m1.x; mp[5] = m1.y; mp[6] = m1.z; mp[7] = m1.w;
+    ep[0] = e0.x; ep[1] = e0.y; ep[2] = e0.z; ep[3] = e0.w; ep[4] = e1.x; ep[5] = e1.y; ep[6] = e1.z; ep[7] = e1.w;
+    dma_row(m + 3);  // into the slot of row m - 5, whose reads have just completed
+  };
+  auto lookup10 = [&](const uint32_t idx[10], uint32_t v[10]) {
+    // the block whose last row is cur_m: rows cur_m - 3 ... cur_m sit in four consecutive slots (cur_m - 3 is a multiple of 4)
+    const uint32_t base = ring_lane_byte + ((uint32_t)(cur_m - 3) & 7u) * 2048u;
+    uint32_t a[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a[i] = base + ((idx[i] & 28u) << 8) + ((idx[i] & 3u) << 2);
+    asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %12\n\tds_read_b32 %3, %13\n\t"
+                 "ds_read_b32 %4, %14\n\tds_read_b32 %5, %15\n\tds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\t"
+                 "ds_read_b32 %8, %18\n\tds_read_b32 %9, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9])
+                 : "memory");
+  };
+  const uint32_t left_wave = (wave_s == 0u ? W : wave_s) - 1u, right_wave = wave_s + 1u == W ? 0u : wave_s + 1u;
+  auto exchange = [&](int s, const PvrtcColors &own, uint32_t col0, PvrtcColors &left, PvrtcColors &right, uint32_t &right_col0) {
+    const uint32_t x = xch_byte + ((uint32_t)s & 1u) * (W * kOnePassXchDwords * 4u);
+    const uint32_t mine = x + wave_s * (kOnePassXchDwords * 4u);
+    const uint2 c = make_uint2(own.a, own.b);
+    if (lane == 0u) asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %0, %2 offset:8" :: "v"(mine), "v"(c), "v"(col0) : "memory");
+    if (lane == 63u) asm volatile("ds_write_b64 %0, %1 offset:16" :: "v"(mine), "v"(c) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint2 l;
+    uint4 r;
+    const uint32_t al = x + left_wave * (kOnePassXchDwords * 4u), ar = x + right_wave * (kOnePassXchDwords * 4u);
+    asm volatile("ds_read_b64 %0, %2 offset:16\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(r) : "v"(al), "v"(ar) : "memory");
+    const uint32_t la = dpp_from_lower_lane(own.a), lb = dpp_from_lower_lane(own.b);
+    const uint32_t ra = dpp_from_upper_lane(own.a), rb = dpp_from_upper_lane(own.b), rc = dpp_from_upper_lane(col0);
+    left.a = lane == 0u ? l.x : la;   left.b = lane == 0u ? l.y : lb;
+    right.a = lane == 63u ? r.x : ra; right.b = lane == 63u ? r.y : rb;
+    right_col0 = lane == 63u ? r.z : rc;
+  };
+  // this lane's slot of block row jj (0..3) in the wave's tile: chunk = lane / 4, Z order inside (x odd bits, y even bits)
+  const uint32_t tile_lane_byte = tile_byte + ((lane >> 2) * kOnePassChunkSlots + (((lane & 1u) | (lane & 2u) << 1) << 1)) * 8u;
+  const uint32_t zx = spread_bits16(bx) << 1;
+  // write-out of four finished block rows: 2 rounds, a lane stores 16 bytes (two Z-adjacent blocks), 8 lanes one 128-byte run
+  uint32_t flush_lds[2], flush_zx[2];
+#pragma unroll
+  for (uint32_t t = 0; t < 2; ++t) {
+    const uint32_t p = t * 64u + lane, chunk = p >> 3, within = (p & 7u) << 1;
+    flush_lds[t] = tile_byte + (chunk * kOnePassChunkSlots + within) * 8u;
+    flush_zx[t] = (spread_bits16(wave_s * 64u + 4u * chunk) << 1) + within;
+  }
+  auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
+    const uint2 v = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
+    if (!L.stage_stores) {
+      asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + (zx | spread_bits16(by0 + j))), "v"(v) : "memory");
+      return;
+    }
+    const uint32_t jj = j & 3u;
+    asm volatile("ds_write_b64 %0, %1" :: "v"(tile_lane_byte + ((jj & 1u) | (jj & 2u) << 1) * 8u), "v"(v) : "memory");
+    if (jj != 3u) return;
+    const uint32_t zy = spread_bits16(by0 + j - 3u);  // a multiple of 4: its bits do not meet `within`
+#pragma unroll
+    for (uint32_t t = 0; t < 2; ++t) {
+      icamd_u32x4 q;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q) : "v"(flush_lds[t]) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst + (flush_zx[t] | zy)), "v"(q) : "memory");
+    }
+  };
+  pvrtc_onepass_strip(K, image0, tick, lookup10, exchange, store);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row requests past the end of the strip
+#if !defined(ICAMD_PVRTC_ONEPASS_NO_VGPR_CLAIM)
+  // Claim 176 VGPRs (the walk uses ~120): LDS already limits a CU to 8 waves, and with at most two waves per SIMD the
+  // dispatcher cannot stack the one- and two-wave workgroups of 512^2 / 1024^2 textures three or four deep on one SIMD while
+  // another idles once workgroups retire out of step (r05 A/B, 256 x 1024^2 in 16-block strips: 0.534 -> 0.425 ms).
+  asm volatile("" ::: "v175");
+#endif
+}
+
+// the kernel whole-texture launches of 512^2 ... 4096^2 take (launch_pvrtc2); smaller / larger / partial ones: morph + encode
+const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_onepass_kernel"; }
 
 namespace {
 // inverse of pvrtc_z_index on the host: x from the odd bits, y from the even bits
@@ -615,9 +760,91 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   return e != hipSuccess ? e : e2;
 }
 
+// ---- path selection: one pass (whole textures of 512^2 ... 4096^2, enough of them to fill the chip) or morph + encode --------
+namespace {
+std::atomic<int> g_path_mode{-1};   // -1: not read yet; 0 auto, 1 always two kernels, 2 one pass wherever it is eligible
+std::atomic<int> g_path_strip{-2};  // -2: not read yet; -1 auto, else log2(blocks per strip) of the one-pass kernel
+void read_path_env() {
+  if (g_path_mode.load() >= 0) return;
+  const char *m = getenv("ICAMD_PVRTC2_PATH"), *k = getenv("ICAMD_PVRTC2_STRIP");
+  int mode = 0;
+  if (m && !strcmp(m, "two")) mode = 1;
+  else if (m && !strcmp(m, "one")) mode = 2;
+  g_path_strip.store(k && *k ? atoi(k) : -1);
+  g_path_mode.store(mode);
+}
+// Strip height of the one-pass kernel for n_images size^2 textures, or -1 where the morph + encode pair is the better choice.
+// Time model, fitted on an MI355X (profiles/r05_ab_pvrtc_onepass.log, within 5 % of every measured shape from 1 x 512^2 to
+// 16 x 4096^2): a workgroup of K-block strips takes 11 + 5.8 K us whatever its width (its waves walk K + 2 block rows at two
+// waves per SIMD), a CU holds 8 / waves-per-workgroup of them, a launch takes ceil(workgroups / slots) such rounds; the pair
+// takes 10 us + 52.6 us per million blocks.  forced >= 0: that strip height; always: the best strip height, no comparison.
+int onepass_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always) {
+  const uint32_t log2_bw = log2_size - 3u, log2_bh = log2_size - 2u;
+  if (log2_bw < 6u || log2_bw > 9u) return -1;  // a workgroup is one block row wide: 64 ... 512 lanes
+  if (forced >= 0) return forced < 2 ? 2 : (forced > (int)log2_bh ? (int)log2_bh : forced);
+  const uint64_t slots = 256ull * (8u >> (log2_bw - 6u));
+  int best = -1;
+  double best_us = 0.0;
+  for (int sb = 2; sb <= 6 && sb <= (int)log2_bh; ++sb) {
+    const uint64_t wgs = n_images << (log2_bh - (uint32_t)sb);
+    const double us = (double)((wgs + slots - 1) / slots) * (11.0 + 5.8 * (double)(1u << sb));
+    if (best < 0 || us <= best_us) { best_us = us; best = sb; }
+  }
+  const double pair_us = 10.0 + 52.6e-6 * (double)(n_images << (log2_bw + log2_bh));
+  return always || best_us < 0.97 * pair_us ? best : -1;
+}
+hipError_t launch_pvrtc2_onepass(const PvrtcParams &P, int sb, hipStream_t stream) {
+  const uint32_t log2_bw = P.log2_size - 3u, bw = 1u << log2_bw, waves = bw >> 6;
+  const size_t lds_bytes = (size_t)waves * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u;
+  // more than 64 KiB of dynamic LDS has to be allowed per function and device, once
+  static std::atomic<uint64_t> allowed{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 64 && !((allowed.load() >> dev) & 1u)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(icamd_pvrtc2_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(8u * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u));
+    if (e != hipSuccess) return e;
+    allowed.fetch_or(1ull << dev);
+  }
+  PvrtcLaunch L;
+  L.src = P.src;
+  L.dst = P.dst;
+  L.ab = nullptr;
+  L.src_image_stride = P.src_image_stride;
+  L.dst_image_stride = P.dst_image_stride;
+  L.size = P.size;
+  L.log2_bw = log2_bw;
+  L.log2_bpi = 2 * P.log2_size - 5;
+  L.log2_strip = (uint32_t)sb;
+  L.rx0 = L.ry0 = L.z_first = 0;
+  L.log2_rw = log2_bw;
+  L.log2_rblocks = L.log2_bpi;
+  L.total_blocks = L.total_strips = 0;
+  // the tile's write-out issues 16-byte stores: only when every image's output is 16-byte aligned (the contract asks for 8)
+  L.stage_stores = (reinterpret_cast<uintptr_t>(P.dst) % 16u == 0 && (P.n_images == 1 || P.dst_image_stride % 16u == 0)) ? 1u : 0u;
+  const uint32_t strips_per_image = (P.size / 4u) >> sb;
+  // (launch_pvrtc2 has checked blocks per image x images < 2^31, so the grid fits)
+  hipLaunchKernelGGL(icamd_pvrtc2_onepass_kernel, dim3((uint32_t)(P.n_images * (uint64_t)strips_per_image)), dim3(bw), lds_bytes, stream, L);
+  return hipGetLastError();
+}
+}  // namespace
+
+void pvrtc2_tune(int mode, int log2_strip) {
+  read_path_env();
+  g_path_mode.store(mode < 0 || mode > 2 ? 0 : mode);
+  g_path_strip.store(log2_strip < 0 ? -1 : log2_strip);
+}
+
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   if (P.n_images == 0) return hipSuccess;
   if (P.region_blocks != 0) return P.n_images == 1 ? launch_pvrtc2_region(P, stream) : hipErrorInvalidValue;
+  read_path_env();
+  if (g_path_mode.load() != 1 && (uint64_t)(P.size / 8) * (P.size / 4) * P.n_images < (1ull << 31)) {
+    const bool force = g_path_mode.load() == 2;  // (a strip height only counts together with mode 2)
+    const int sb = onepass_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force);
+    if (sb >= 0) return launch_pvrtc2_onepass(P, sb, stream);
+  }
   const uint32_t bw = P.size / 8, bh = P.size / 4;
   const uint64_t bpi = (uint64_t)bw * bh;
   // Images per launch pair.  Every launch boundary costs a drain/fill of ~4 waves per SIMD: measured 0.67 / 0.60 /

@@ -104,6 +104,15 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
 size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images);
 int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes);
 
+/* PVRTC kernel selection (EXTENSION, tuning / test hook; results are identical either way).  Whole textures of 512^2 ...
+ * 4096^2 in launches large enough to fill the chip take the one-pass kernel (Morph, Modulate and Encode of
+ * pvrtc_compressor.cc:586-597 in ONE read of the pixels, no scratch memory -- such launches can be captured into a HIP graph
+ * without a caller-owned workspace); everything else takes the morph + encode pair.  mode 0 = automatic (default; also the
+ * value of the environment variable ICAMD_PVRTC2_PATH=auto|two|one read at the first launch), 1 = always the pair, 2 = one pass
+ * wherever eligible; log2_strip < 0 = automatic strip height (blocks per lane) of the one-pass kernel, else 2 ... 6.
+ * Process-wide.  Returns ICAMD_OK, or ICAMD_ERR_ARG for a mode outside 0 ... 2. */
+int icamd_pvrtc2_tune(int mode, int log2_strip);
+
 /* ---- the hot path, device-resident (the roofline entry points) ----
  * Same contracts, but `d_buffer` / `d_out` are device pointers on the current HIP
  * device and the work is enqueued on `hip_stream` (a hipStream_t, NULL = default

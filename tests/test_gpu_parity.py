@@ -297,6 +297,120 @@ def test_pvrtc_large_batches(pkg):
             assert hashlib.sha256(out[i].cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(want).hexdigest(), (n, size, i)
 
 
+@pytest.fixture
+def pvrtc_auto(pkg):
+    """icamd_pvrtc2_tune is process-wide: whatever a test forces, the automatic selection is back afterwards."""
+    yield
+    assert pkg.pvrtc_tune(0, -1)
+
+
+def test_pvrtc_onepass_kernel_every_strip_height_matches_oracle(pkg, pvrtc_auto):
+    """r05: icamd_pvrtc2_onepass_kernel (morph + modulate + encode in one read of the pixels; one workgroup = one whole
+    block row of the texture wide, 1 / 2 / 4 / 8 waves) forced for every eligible size and every strip height, against the
+    oracle: all contents, the image-pixel-0 rule, a batch with padded image strides, an 8-mod-16 destination (no staged
+    stores) -- and the same inputs through the morph + encode pair."""
+    import ctypes
+    import torch
+    for n in (512, 1024, 2048):
+        imgs = [T.GENERATORS[gen](n, n, 4, index=n + 1) for gen in ("noise", "smooth", "flat", "mixed")]
+        z = np.zeros((n, n, 4), np.uint8)  # never-updated maxima refer to image pixel 0 (pvrtc.cc:268-269)
+        z[0, 0] = (250, 3, 7, 255)
+        z[n // 4:, :, 1] = 200
+        z[:, n // 2:, 3] = 255
+        imgs.append(z)
+        want = [T.oracle_encode(T.PVRTC2, im, n, n, 4, threads=8) for im in imgs]
+        d = _dev(np.stack(imgs))
+        for mode, strips in ((1, (-1,)), (2, (2, 3, 4, 5, 6))):
+            for sb in strips:
+                assert pkg.pvrtc_tune(mode, sb)
+                out = pkg.encode_device(T.PVRTC2, d, n, n, 4, n_images=len(imgs))
+                torch.cuda.synchronize()
+                for i in range(len(imgs)):
+                    assert out[i].cpu().numpy().tobytes() == want[i], (n, mode, sb, i)
+                one = pkg.encode_device(T.PVRTC2, d[3], n, n, 4)  # one texture per call
+                assert _host(one) == want[3], (n, mode, sb)
+    # 4096^2 (eight waves per workgroup): one mixed texture, every strip height
+    n = 4096
+    img = T.s_smooth(n, n, 4, index=16)
+    img[:1024, :1024] = T.s_noise(1024, 1024, 4, index=16)
+    img[1024:2048, 2048:] = T.s_flat(1024, 2048, 4, index=16)
+    want = hashlib.sha256(T.oracle_encode(T.PVRTC2, img, n, n, 4, threads=8)).hexdigest()
+    d = _dev(img)
+    for sb in (2, 3, 4, 5, 6):
+        assert pkg.pvrtc_tune(2, sb)
+        assert hashlib.sha256(_host(pkg.encode_device(T.PVRTC2, d, n, n, 4))).hexdigest() == want, sb
+    # padded image strides on both sides, and a destination that is only 8-byte aligned
+    n, cnt = 1024, 3
+    per = n * n // 4
+    imgs = np.stack([T.s_mixed(n, n, 4, index=40 + i) for i in range(cnt)])
+    want = [T.oracle_encode(T.PVRTC2, imgs[i], n, n, 4, threads=8) for i in range(cnt)]
+    src = torch.zeros((cnt, n * n * 4 + 4096), dtype=torch.uint8, device="cuda")
+    src[:, : n * n * 4] = _dev(imgs).view(cnt, -1)
+    for off, dst_stride in ((0, per + 256), (8, per + 8), (8, per + 16)):
+        buf = torch.zeros(cnt * dst_stride + 64, dtype=torch.uint8, device="cuda")
+        for mode, sb in ((2, 3), (2, 5), (1, -1)):
+            assert pkg.pvrtc_tune(mode, sb)
+            buf.zero_()
+            st = pkg.lib().icamd_encode_device(T.PVRTC2, 2, 4, 0, n, n, n, n, n * 4, cnt, n * n * 4 + 4096, dst_stride,
+                                               ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(buf.data_ptr() + off), None)
+            assert st == 0
+            torch.cuda.synchronize()
+            host = buf.cpu().numpy()
+            for i in range(cnt):
+                assert host[off + i * dst_stride: off + i * dst_stride + per].tobytes() == want[i], (off, dst_stride, mode, sb, i)
+            assert not host[off + (cnt - 1) * dst_stride + per:].any() and not host[:off].any()
+
+
+def test_pvrtc_automatic_path_selection_and_both_paths_on_a_full_batch(pkg, pvrtc_auto):
+    """The launch shapes BASELINE config 5 is quoted on (16 x 4096^2) and its neighbours: the automatic selection, the
+    forced pair and the forced one-pass kernel produce the same bytes; texture 0 and the last one against the oracle."""
+    import torch
+    for n, size in ((16, 4096), (64, 2048), (256, 1024), (600, 512), (3, 4096), (1, 2048)):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(size * 3 + n)
+        src = torch.randint(0, 256, (n, size, size, 4), dtype=torch.uint8, device="cuda", generator=g)
+        src[1::3, :, :, 3] = 255
+        src[2::3] = (src[2::3] >> 3) + 100
+        outs = []
+        for mode in (0, 1, 2):
+            assert pkg.pvrtc_tune(mode, -1)
+            outs.append(pkg.encode_device(T.PVRTC2, src, size, size, 4, n_images=n).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (n, size)
+        for i in (0, n - 1):
+            want = T.oracle_encode(T.PVRTC2, src[i].cpu().numpy(), size, size, 4, threads=8)
+            assert outs[0][i].cpu().numpy().tobytes() == want, (n, size, i)
+
+
+def test_pvrtc_onepass_launches_can_be_captured_without_a_workspace(pkg, pvrtc_auto):
+    """The one-pass kernel keeps nothing between kernels, so a launch that takes it can be captured into a HIP graph with
+    no caller-owned workspace (the pair refuses that, test_pvrtc_graphs_keep_their_own_workspace)."""
+    import torch
+    n, size = 4, 1024
+    imgs = np.stack([T.s_mixed(size, size, 4, index=900 + i) for i in range(n)])
+    d = _dev(imgs)
+    out = torch.zeros((n, size * size // 4), dtype=torch.uint8, device="cuda")
+    assert pkg.pvrtc_tune(2, -1)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            assert pkg.encode_device(T.PVRTC2, d, size, size, 4, n_images=n, out=out, stream=s) is not None
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            s.synchronize()
+            for i in range(n):
+                assert out[i].cpu().numpy().tobytes() == T.oracle_encode(T.PVRTC2, imgs[i], size, size, 4, threads=8), i
+    assert pkg.pvrtc_tune(1, -1)
+    with torch.cuda.stream(s):
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(pkg.BackendError):
+            with torch.cuda.graph(g2, stream=s):
+                pkg.encode_device(T.PVRTC2, d, size, size, 4, n_images=n, out=out, stream=s)
+    torch.cuda.synchronize()
+
+
 def test_const_colour_table_as_compiled_into_the_library(pkg):
     """the oracle and the product compile in the SAME dxtc_const_table.inc, so a corrupted table would
     pass every product-vs-oracle test.  Pin it without the oracle: (1) the file's 2 048 values hash to the pinned SHA-256;

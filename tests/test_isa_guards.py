@@ -88,3 +88,46 @@ def test_pvrtc_register_path_build_still_compiles(tmp_path):
     ever breaks the guard above: keep it building and spill-free."""
     text = _asm("pvrtc_kernels.hip", tmp_path, ["-DICAMD_PVRTC_NO_ROW_DMA"])
     assert _kernel_meta(text, "icamd_pvrtc2_encode_kernel")["scratch"] == 0
+
+
+def test_pvrtc_onepass_kernel_ring_protocol_as_compiled(tmp_path):
+    """icamd_pvrtc2_onepass_kernel (r05) counts its waits by hand too: every tick of the strip walk issues exactly ONE pixel
+    row (two global_load_lds) and waits with `s_waitcnt vmcnt(4)` -- the two youngest rows may be in flight, everything
+    older has landed.  That only holds while hipcc adds no memory operation of its own to the walk: any LDS access or load
+    it could see would come with a vmcnt(0) that drains the ring (a performance bug), a hoisted or duplicated DMA would
+    break the count (a correctness bug).  Checked on the emitted assembly: no scratch; the 176-VGPR claim that caps a SIMD
+    at two waves is in the descriptor; the loop body holds exactly 4 ticks' worth of DMA and waits, one barrier, and no
+    other vmcnt wait; every LDS / memory instruction of the kernel sits inside an inline-asm region or is a DMA."""
+    text = _asm("pvrtc_kernels.hip", tmp_path)
+    meta = _kernel_meta(text, "icamd_pvrtc2_onepass_kernel")
+    assert meta["scratch"] == 0
+    assert 171 <= meta["vgprs"] <= 256, meta
+    assert meta["lds"] == 0  # the ring is dynamic LDS, sized per workgroup width by the launcher
+    body = _body(text, "icamd_pvrtc2_onepass_kernel")
+    loop = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    back = max(i for i, l in enumerate(body) if re.match(r"\s+s_cbranch_\w+\s+\.LBB\d+_\d+", l))
+    in_asm, stray = False, []
+    for i, l in enumerate(body):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif re.match(r"\s+(ds_|global_|buffer_|flat_|scratch_)", l) and not in_asm and "global_load_lds" not in l:
+            stray.append(l.strip())
+    assert not stray, "memory / LDS instructions outside the inline asm of the walk: %s" % stray[:4]
+    pre = [l for l in body[:loop] if "global_load_lds_dwordx4" in l]
+    assert len(pre) == 6 + 3 * 2, "prologue: three rows up front + the three morph-only ticks (got %d DMA instructions)" % len(pre)
+    walk = body[loop:back + 1]
+    dma = sum("global_load_lds_dwordx4" in l for l in walk)
+    waits = [re.sub(r"\s+", " ", l.strip()) for l in walk if "s_waitcnt" in l and "vmcnt" in l]
+    assert dma == 8, dma
+    assert waits == ["s_waitcnt vmcnt(4)"] * 4, waits
+    assert sum(bool(re.match(r"\s+s_barrier", l)) for l in walk) == 1
+    tail = [re.sub(r"\s+", " ", l.strip()) for l in body[back + 1:] if "s_waitcnt" in l and "vmcnt" in l]
+    assert tail == ["s_waitcnt vmcnt(0)"], tail
+
+
+def test_pvrtc_onepass_kernel_plain_scan_build_still_compiles(tmp_path):
+    """-DICAMD_PVRTC_NO_SCAN_SDWA (the early-exit scan as plain C++ instead of the VCC / SDWA sequence) stays buildable."""
+    text = _asm("pvrtc_kernels.hip", tmp_path, ["-DICAMD_PVRTC_NO_SCAN_SDWA"])
+    assert _kernel_meta(text, "icamd_pvrtc2_onepass_kernel")["scratch"] == 0
