@@ -523,7 +523,7 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     }
 
 
-def valu_fraction(args, codec, pixels_per_launch, kernel_ms, clock_mhz):
+def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, kernel_ms, clock_mhz, preset=None):
     """Integer-VALU issue fraction of the sustained run, from measured quantities only:
       executed VALU wave-instructions per kernel  -- SQ_INSTS_VALU of the committed PMC profile of EXACTLY this workload /
                                                     content / ETC strategy (profiles/valu_insts.json);
@@ -537,7 +537,10 @@ def valu_fraction(args, codec, pixels_per_launch, kernel_ms, clock_mhz):
     if not os.path.exists(vpath):
         return None
     with open(vpath) as f:
-        vi = json.load(f).get("%s/%s/s%d" % (args.workload, args.content, args.etc_strategy if codec == 2 else 0))
+        table = json.load(f)
+        # a profile of EXACTLY the preset's launch shape and content first (c4: the ETC1 search is content- and size-dependent)
+        vi = (table.get("preset:%s/%s/s%d" % (preset, content, etc_strategy if codec == 2 else 0)) if preset else None) or \
+            table.get("%s/%s/s%d" % (workload, content, etc_strategy if codec == 2 else 0))
     if not vi:
         return None
     isa = {}
@@ -563,6 +566,114 @@ def valu_fraction(args, codec, pixels_per_launch, kernel_ms, clock_mhz):
             "valu_clock_MHz": mhz if clock_mhz else "2400 nominal (no probe)",
             "valu_frac_note": "executed VALU wave-instructions x issue clocks (4; 2 for full-rate ops, static mix) / "
                               "(1024 SIMDs x measured shader clock x sustained kernel time)"}
+
+
+def host_api_batch_leg(pkg, T, n_images=32, size=2048):
+    """icamd_compress_batch (C callers without torch.distributed): 32 x 2048^2 kRGB -> DXT1 from pageable host
+    buffers, one host worker thread (own stream + staging buffers) per device-list entry, on device lists [0] and [0, 0].
+    The C entry point itself is timed (pointer lists and touched output buffers prepared once), not the Python convenience
+    wrapper around it, whose fresh numpy outputs page-fault underneath the D2H copies."""
+    import ctypes
+    import numpy as np
+    batch = [T.s_noise(size, size, 3, index=300 + i).reshape(-1) for i in range(n_images)]
+    want = T.oracle_compress(T.DXTC, T.RGB, batch[0].reshape(size, size, 3), size, size, 0, 2)
+    out_size = pkg.compute_compressed_data_size(pkg.COMPRESSOR_DXTC, pkg.RGB, size, size)
+    outs = [np.ones(out_size, np.uint8) for _ in range(n_images)]
+    in_ptrs = (ctypes.c_void_p * n_images)(*[b.ctypes.data for b in batch])
+    out_ptrs = (ctypes.c_void_p * n_images)(*[o.ctypes.data for o in outs])
+    statuses = (ctypes.c_int * n_images)()
+    res = {"entry_point": "icamd_compress_batch", "images": n_images, "texture": [size, size], "format": "kRGB", "codec": "DXT1"}
+    for devices in ([0], [0, 0]):
+        devs = (ctypes.c_int * len(devices))(*devices)
+
+        def call():
+            st = pkg.lib().icamd_compress_batch(pkg.COMPRESSOR_DXTC, 2, pkg.RGB, size, size, 0, n_images, in_ptrs, out_ptrs,
+                                                out_size, devs, len(devices), statuses)
+            assert st == 0 and all(s == 0 for s in statuses)
+        call()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
+        res["devices_%s" % "_".join(str(d) for d in devices)] = {
+            "ms_per_batch": round(dt * 1e3, 3), "value": round(n_images * size * size / dt / 1e6, 1), "unit": "Mpixels/s",
+            "source_GBps": round(n_images * size * size * 3 / dt / 1e9, 2),
+            "parity": "bit-exact vs oracle (image 0)" if outs[0].tobytes() == want else "MISMATCH vs oracle"}
+    return res
+
+
+def clock_under_load(torch, pkg, step, kernel_ms, launches):
+    """Effective shader clock while `launches` more launches of `step` run (the one-wave probe of the sustained leg, on a
+    second stream): every extra-config leg reports the clock its figure was taken at."""
+    try:
+        buf = pkg.clock_probe_buffer()
+        ps = torch.cuda.Stream()
+        res = pkg.clock_probe(max(200, int(kernel_ms * 1e3 * launches * 0.8)), ps, buf)
+        for _ in range(launches):
+            step()
+        torch.cuda.synchronize()
+        r = res()
+        return round(r["shader_MHz"], 1) if r else None
+    except Exception:
+        return None
+
+
+def link_probe(ctx, mib=64, reps=3):
+    """What a gather into rank 0 can reach on this node, measured: every peer alone sending `mib` MiB to rank 0 (one xGMI
+    link under RCCL; host-staged under gloo) and all peers at once (rank 0's inbound links together).  The gathers of the
+    `value_with_gather` figures cannot beat the second number whatever the encoders do."""
+    if not ctx.distributed or ctx.world < 2:
+        return None
+    torch, dist, world, rank = ctx.torch, ctx.dist, ctx.world, ctx.rank
+    staged = ctx.backend == "gloo"
+    dev = "cpu" if staged else ctx.device
+    n = mib << 20
+    buf = torch.full((n,), rank & 255, dtype=torch.uint8, device=dev)
+    recv = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+
+    def timed(fn):
+        fn()  # connection set-up
+        ctx.sync(); ctx.barrier(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync(); ctx.barrier(); ctx.sync()
+        return ctx.max_over_ranks(time.perf_counter() - t0) / reps
+    alone = []
+    for peer in range(1, world):
+        def one(peer=peer):
+            if rank == 0:
+                dist.recv(recv[peer], src=peer)
+            elif rank == peer:
+                dist.send(buf, dst=0)
+        alone.append(round(n / timed(one) / 1e9, 2))
+
+    def everyone():
+        dist.gather(buf, recv, dst=0)
+    together = (world - 1) * n / timed(everyone) / 1e9
+    ok = True
+    if rank == 0:
+        ok = all(int(recv[r][0].item()) == (r & 255) and int(recv[r][-1].item()) == (r & 255) for r in range(1, world))
+    return {"backend": ctx.backend + (" (tensors staged through host memory: not an xGMI figure)" if staged else " (RCCL)"),
+            "payload_MiB_per_peer": mib, "per_peer_alone_GBps": alone, "all_peers_at_once_GBps_into_rank0": round(together, 2),
+            "peers": world - 1, "xgmi_links_into_rank0": min(world - 1, 7), "payload_intact": ok}
+
+
+def gather_bound(probe, out_bytes_all, world, pixels_per_step_all):
+    """Fields that make a value_with_gather figure interpretable: how many ranks gather, how many bytes enter rank 0 per step,
+    the measured inbound rate that bounds it, and the Mpixels/s ceiling that rate implies."""
+    inbound = out_bytes_all * (world - 1) / world
+    d = {"gather_ranks": world, "gather_bytes_into_rank0_per_step": int(inbound)}
+    if probe:
+        rate = probe["all_peers_at_once_GBps_into_rank0"]
+        d["gather_bound_GBps"] = rate
+        d["value_with_gather_ceiling"] = round(pixels_per_step_all / (inbound / (rate * 1e9)) / 1e6, 1) if inbound and rate else None
+    else:
+        d["gather_bound_GBps"] = None
+        d["value_with_gather_ceiling"] = None
+    return d
 
 
 class Ctx:
@@ -652,7 +763,7 @@ def preset_traffic(preset, workload, size, batch):
     return None, None
 
 
-def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, gather=True):
+def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, gather=True, probe=None):
     """One BASELINE configuration other than the headline one, as a compact object for the `configs` field of the line:
     the same timed region (K steps between barriers, MAX over ranks), roofline of the dominant kernel from HIP events,
     parity of texture 0 against the oracle, and for N > 1 the gather of the compressed output to rank 0."""
@@ -685,7 +796,8 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
         try:
             counts = [e - b for b, e in (sharding.texture_range(cfg["total_textures"], ctx.world, r) for r in range(ctx.world))] \
                 if cfg.get("total_textures") else [batch] * ctx.world
-            res.update(gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, steps, stream, px_all, codec))
+            res.update(gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, steps, stream, px_all, codec,
+                                     probe))
         except Exception as e:
             res.update({"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)})
     if ctx.rank == 0:
@@ -696,6 +808,12 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
                            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": source,
                            "kernel": pkg.kernel_name(codec, comps), "kernel_ms": round(kernel_ms, 4),
                            "algorithmic_bytes_per_launch": int(algo)}
+        # the clock this figure was taken at (DXT5 moves 835 <-> 1 264 Gpix/s with it, r04) and the VALU issue fraction
+        mhz = clock_under_load(torch, pkg, step, kernel_ms, max(steps, int(30.0 / max(kernel_ms, 1e-3)))) if ctx.on_gpu else None
+        res["roofline"]["effective_clock_MHz"] = mhz
+        vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, kernel_ms, mhz, preset=name)
+        if vf:
+            res["roofline"].update({k: vf[k] for k in ("valu_frac", "valu_wave_insts_per_block", "valu_profile", "valu_clock_MHz")})
         if verify:
             import ic_testlib as T
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
@@ -710,7 +828,7 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
     return res
 
 
-def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_per_step_all, codec):
+def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_per_step_all, codec, probe=None):
     """encode -> gather of the compressed output on rank 0, the gather of batch k on a second stream underneath
     the encode of batch k + 1 (double-buffered).  step_into(slot) encodes into outs[slot]."""
     torch = ctx.torch
@@ -755,7 +873,8 @@ def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_
         ok = bool(torch.equal(last[0], outs[(steps - 1) & 1]))
     out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
     world = ctx.world
-    return {"value_with_gather": round(pixels_per_step_all * steps / elapsed_g / 1e6, 1),
+    bound = gather_bound(probe, out_bytes_all, world, pixels_per_step_all)
+    return {**bound, "value_with_gather": round(pixels_per_step_all * steps / elapsed_g / 1e6, 1),
             "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4), "gather_ms": round(gather_ms, 4),
             "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
             "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, overlapping the "
@@ -763,14 +882,17 @@ def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_
             "rank0_copy_matches": ok}
 
 
-def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=True, oracle_encode=None):
+def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=True, oracle_encode=None, probe=None,
+             rotate_bytes=320 << 20, rotate_min=5, rotate_max=64):
     """ONE size x size image split into contiguous slabs of block rows over the ranks (blocks are stored
     row-major, compressor4x4_helper.h:202-214, so every slab's blocks are one contiguous byte range of the final buffer):
-    strong scaling.  Every rank holds only its slab of the source.  Timed: (1) K encode steps between barriers -> value;
-    (2) K steps of encode -> gather of the slabs into rank 0's final buffer (views of ONE contiguous allocation; equal
-    slabs: one dist.gather, unequal: batched isend / irecv), each step waiting for its gather -> value_with_gather, the
-    latency-shaped figure for one image.  Parity: every rank checks its slab against the oracle's encoding of the same
-    rows (blocks are independent), rank 0 additionally checks the gathered image."""
+    strong scaling.  Every rank holds only its slab of the source -- of `n_rot` DISTINCT images (>= 5 and >= 320 MiB of slabs
+    per rank, r05: one 64 MiB image, or a rank's 8 MiB share of it, re-encoded every step would be read from the 256 MiB
+    Infinity Cache, not from HBM), step i encoding the slab of image i mod n_rot.  Timed: (1) K encode steps between barriers
+    -> value; (2) K steps of encode -> gather of the slabs into rank 0's final buffer (views of ONE contiguous allocation;
+    equal slabs: one dist.gather, unequal: batched isend / irecv), each step waiting for its gather -> value_with_gather, the
+    latency-shaped figure for one image.  Parity: every rank checks its slab of image 0 against the oracle's encoding of the
+    same rows (blocks are independent), rank 0 additionally checks the gathered image."""
     torch = ctx.torch
     codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[workload]
     block_bytes = 16 if codec == 1 else 8
@@ -778,19 +900,27 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
     geos = [sharding.slab_geometry(size, size, comps, stride, block_bytes, ctx.world, r) for r in range(ctx.world)]
     geo = geos[ctx.rank]
     rows, brows, cols = geo["pixel_rows"], geo["block_rows"], (size + 3) // 4
-    src = make_batch(torch, content, 1, size, comps, ctx.device, seed=2000 + ctx.rank, height=max(rows, 4), row0=geo["pixel_row0"])
+    # the same number of distinct images on every rank (rank 0's slab sets it; slabs differ by at most one block row)
+    slab_bytes = max(1, geos[0]["pixel_rows"] * stride)
+    n_rot = int(max(rotate_min, min(rotate_max, -(-rotate_bytes // slab_bytes))))
+    src = make_batch(torch, content, n_rot, size, comps, ctx.device, seed=2000 + ctx.rank, height=max(rows, 4), row0=geo["pixel_row0"])
     out = torch.empty((max(brows, 1), cols * block_bytes), dtype=torch.uint8, device=ctx.device)[:brows]
     stream = ctx.current_stream()
+    turn = [0]
 
-    def step():
+    def step(k=None):
         if rows == 0:
             return
-        r = pkg.encode_device(codec, src, rows, size, comps, n_images=1, out=out.view(1, -1), stream=stream)
+        if k is None:
+            k = turn[0] % n_rot
+            turn[0] += 1
+        r = pkg.encode_device(codec, src[k], rows, size, comps, n_images=1, out=out.view(1, -1), stream=stream)
         assert r is not None
     elapsed, kernel_ms = timed_steps(ctx, step, steps, 3, 0.1, stream)
     px = float(size) * size
     res = {"image": [size, size], "codec": workload, "shard": "block-row slabs (sharding.slab_geometry), one per rank",
            "slab_block_rows": [g["block_rows"] for g in geos], "scaling": "strong", "steps": steps,
+           "distinct_images_rotated": n_rot, "distinct_source_MiB_per_rank": (n_rot * rows * stride) >> 20,
            "value": round(px * steps / elapsed / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(elapsed / steps * 1e3, 4)}
     counts = [g["block_rows"] for g in geos]
     final = torch.empty((sum(counts), cols * block_bytes), dtype=torch.uint8, device=ctx.device) if ctx.rank == 0 else None
@@ -798,11 +928,13 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
     if ctx.rank == 0:
         offs = [g["block_row0"] for g in geos]
         bufs = [final[o:o + c] for o, c in zip(offs, counts)]  # contiguous row ranges of the final image
+
+    def encode_and_gather(k=None):
+        step(k)
+        sharding.gather_to_root(out, bufs, counts, ctx.rank, host_staged=(ctx.backend == "gloo" and ctx.on_gpu))
     try:
-        def encode_and_gather():
-            step()
-            sharding.gather_to_root(out, bufs, counts, ctx.rank, host_staged=(ctx.backend == "gloo" and ctx.on_gpu))
         elapsed_g, _ = timed_steps(ctx, encode_and_gather, steps, 2, 0.0, stream)
+        res.update(gather_bound(probe, float(sum(counts)) * cols * block_bytes, ctx.world, px))
         res.update({"value_with_gather": round(px * steps / elapsed_g / 1e6, 1),
                     "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4),
                     "gather": "slabs -> rank 0's final buffer (contiguous views), %s, not overlapped: one image's latency"
@@ -815,21 +947,30 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
                                  "frac": round(algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "kernel_ms": round(kernel_ms, 5)}
     if verify:
         ok = 1.0
-        if rows:
+        gathered = res.get("value_with_gather") is not None
+        try:  # image 0 once more, untimed: what the checks below look at (every rank takes part in the gather)
+            if gathered:
+                encode_and_gather(0)
+            else:
+                step(0)
+            ctx.sync()
+        except Exception:
+            ok = 0.0
+        if rows and ok:
             if oracle_encode is None:
                 import ic_testlib as T
                 cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
                 oracle_encode = lambda a, h, w: T.oracle_encode(codec, a, h, w, comps, threads=max(1, cores // max(1, ctx.world)))  # noqa: E731
             want = oracle_encode(src[0, :rows].cpu().numpy(), rows, size)
             ok = 1.0 if out.cpu().numpy().tobytes() == want else 0.0
-            if ctx.rank == 0 and final is not None and ok:
+            if ctx.rank == 0 and final is not None and ok and gathered:
                 ok = 1.0 if final[:brows].cpu().numpy().tobytes() == want else 0.0
         # the slabs of the OTHER ranks inside rank 0's gathered image: position-weighted byte checksums, compared on rank 0
         def checksum(t):
             v = t.reshape(-1).to(torch.int64)
             return float(((v + 1) * (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1)).sum().item() % (1 << 52))
         mine = checksum(out) if brows else 0.0
-        if ctx.distributed and res.get("value_with_gather") is not None:
+        if ctx.distributed and gathered:
             sums = torch.zeros(ctx.world, dtype=torch.float64, device=ctx.device if (ctx.backend == "nccl" and ctx.on_gpu) else "cpu")
             sums[ctx.rank] = mine
             ctx.dist.all_reduce(sums, op=ctx.dist.ReduceOp.SUM)
@@ -838,7 +979,7 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
                     if counts[r] and checksum(bufs[r]) != float(sums[r].item()):
                         ok = 0.0
         ok = ctx.min_over_ranks(ok)
-        res["parity"] = "bit-exact vs oracle (every rank's slab); gathered image on rank 0 checked slab by slab (checksums)" \
+        res["parity"] = "bit-exact vs oracle (every rank's slab of image 0); gathered image on rank 0 checked slab by slab (checksums)" \
             if ok == 1.0 else "MISMATCH"
     del src, out, final, bufs
     if ctx.on_gpu:
@@ -897,7 +1038,9 @@ def main():
     barrier = ctx.barrier
 
     if args.shard == "slab":  # ONE large image over the ranks: the headline line of this mode
-        res = slab_leg(ctx, pkg, sharding, args.workload, args.size, args.steps, args.content, verify=not args.no_verify)
+        probe = link_probe(ctx) if distributed else None
+        res = slab_leg(ctx, pkg, sharding, args.workload, args.size, args.steps, args.content, verify=not args.no_verify, probe=probe)
+        res["link_probe"] = probe
         if rank == 0:
             codec, comps, bytes_per_px, label, limiting_unit = WORKLOADS[args.workload]
             tex = "%dx%d %s" % (args.size, args.size, "RGBA8" if comps == 4 else "RGB888")
@@ -972,13 +1115,19 @@ def main():
 
     # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
     gather = None
+    probe = None
     if distributed and not args.no_gather:
+        try:
+            probe = link_probe(ctx)
+        except Exception as e:
+            probe = None
+            print("bench.py: link probe failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
         try:
             counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
                 else [(r * batch, (r + 1) * batch) for r in range(world)]
             counts = [e - b for b, e in counts]
             gather = gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, args.steps, stream,
-                                   pixels_per_step_all, codec)
+                                   pixels_per_step_all, codec, probe)
         except Exception as e:  # the encode-only line must survive a failing gather (it is reported, not hidden)
             gather = {"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)}
 
@@ -1002,6 +1151,13 @@ def main():
     }
     if gather is not None:
         result.update(gather)
+    result["link_probe"] = probe
+    result["scaling_headline"] = (
+        "`value` (every rank's compressed output stays in the HBM of the GPU that made it -- the texture pipeline's normal case) "
+        "is the figure to compute scaling efficiency from.  `value_with_gather` additionally moves every rank's blocks into "
+        "rank 0 (SURVEY 8d): (N-1)/N of the output enters ONE GPU through its min(N-1, 7) inbound xGMI links, so it is bound by "
+        "`gather_bound_GBps` (measured here by link_probe; null on one rank) at `value_with_gather_ceiling` whatever the encoders "
+        "do, and for HBM-bound DXT1 that ceiling lies BELOW the 1-GPU `value`.")
 
     if rank == 0:
         algo_bytes = pixels_per_step_rank * bytes_per_px
@@ -1044,6 +1200,11 @@ def main():
                 result["host_api"] = host_api_leg(pkg, T, codec, size, args.etc_strategy)
             except Exception as e:
                 result["host_api"] = "unavailable: %s" % e
+            if isinstance(result["host_api"], dict):
+                try:
+                    result["host_api"]["batch"] = host_api_batch_leg(pkg, T)
+                except Exception as e:
+                    result["host_api"]["batch"] = "unavailable: %s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_sustained:
             try:
                 sus, clock = sustained_leg(torch, pkg, lambda i: step(outs[0]), stream, kernel_ms, args.sustained_seconds,
@@ -1055,7 +1216,8 @@ def main():
                 mhz = (clock.get("last_25pct") or {}).get("shader_MHz")
                 if mhz:
                     result["roofline"]["effective_clock_MHz"] = mhz
-                vf = valu_fraction(args, codec, pixels_per_step_rank, sus["median_ms_last_20pct"], mhz)
+                vf = valu_fraction(args.workload, args.content, args.etc_strategy, codec, pixels_per_step_rank,
+                                   sus["median_ms_last_20pct"], mhz)
                 if vf:
                     result["roofline"].update(vf)
             except Exception as e:
@@ -1079,15 +1241,30 @@ def main():
             for name in ("c3", "c4", "c5"):
                 try:
                     configs[name] = preset_leg(ctx, pkg, sharding, name, args.extra_steps, verify=not args.no_verify,
-                                               gather=not args.no_gather)
+                                               gather=not args.no_gather, probe=probe)
                 except Exception as e:  # a failing extra leg is reported, it does not take the headline down
                     configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                if name == "c4" and "error" not in configs[name]:
+                    # the ETC1 search is content-dependent (smooth gradients clamp at base +- b: 27 % slower than the noise the
+                    # configuration is quoted on; flat tiles take the one-colour forms): the same leg on the other two contents
+                    other = {}
+                    for content in ("smooth", "flat"):
+                        try:
+                            r = preset_leg(ctx, pkg, sharding, name, max(2, args.extra_steps // 2), content=content,
+                                           verify=not args.no_verify, gather=False)
+                            other[content] = {k: r.get(k) for k in ("value", "unit", "ms_per_step", "steps", "parity", "data")}
+                            rf = r.get("roofline") or {}
+                            other[content].update({k: rf.get(k) for k in ("frac", "valu_frac", "effective_clock_MHz", "kernel_ms",
+                                                                           "valu_wave_insts_per_block")})
+                        except Exception as e:
+                            other[content] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    configs[name]["other_contents"] = other
             result["configs"] = configs
         if not args.no_slab:
             slabs = {}
             for key, wl, sz in (("c2_one_4096", "dxt1_rgba8", 4096), ("c3_one_8192", "dxt5_rgba8", 8192), ("one_16384", "dxt1_rgba8", 16384)):
                 try:
-                    slabs[key] = slab_leg(ctx, pkg, sharding, wl, sz, args.extra_steps, verify=not args.no_verify)
+                    slabs[key] = slab_leg(ctx, pkg, sharding, wl, sz, args.extra_steps, verify=not args.no_verify, probe=probe)
                 except Exception as e:
                     slabs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["slab"] = slabs

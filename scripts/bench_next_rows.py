@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
 """Device-resident throughput of the SURVEY 8f "next" rows: block decoders, Downsample, Pad, DXT1->ETC1 transcode.
-Prints one line per kernel: Mpixels/s (source or result pixels, whichever is larger) and algorithmic GB/s."""
+Prints one line per kernel: Mpixels/s (source or result pixels, whichever is larger) and algorithmic GB/s, and (r05) the
+parity of image 0 of exactly the timed call against the oracle (tests/ic_testlib: test infrastructure, the checker only)."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import ic_amd_loader
 pkg = ic_amd_loader.load_package()
+import ic_testlib as T
 L = pkg.lib()
+BAD = []
+
+def parity(what, got, want):
+    """got: device tensor (image 0 of the timed call's output), want: the oracle's bytes."""
+    torch.cuda.synchronize()
+    ok = want is not None and got.cpu().numpy().tobytes() == want
+    if not ok:
+        BAD.append(what)
+    return "parity: bit-exact vs oracle (image 0)" if ok else "parity: MISMATCH vs oracle"
 dev = torch.device("cuda:0")
 n, batch = 4096, 16
 stream = torch.cuda.current_stream()
@@ -37,8 +48,10 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         assert rc == 0
     t = timeit(dec)
     px = batch * n * n
-    print("decode %-5s %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)" % (
-        name, px / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n))
+    b0 = blocks[0].cpu().numpy().tobytes()
+    print("decode %-5s %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s" % (
+        name, px / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
+        parity("decode " + name, out[0], T.oracle_decode(codec, b0, n, n).tobytes())))
     # Downsample / Pad / transcode work on one image's grid per call: loop over the batch inside the timed region
     compressor, fmt = (1, 0) if codec == 2 else (0, 0 if codec == 0 else 2)
     dn = torch.empty((batch, per_in // 4), dtype=torch.uint8, device=dev)
@@ -48,8 +61,9 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
                                            ctypes.c_void_p(dn[i].data_ptr()), dn.shape[1], sh)
             assert rc == 0
     t = timeit(down, 5)
-    print("downsample %-5s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)" % (
-        name, px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
+    print("downsample %-5s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)  %s" % (
+        name, px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch,
+        parity("downsample " + name, dn[0], T.oracle_downsample(compressor, fmt, b0, n, n, 2))))
     # the same as ONE batched launch (icamd_downsample_batch_device, r04), per ETC1 re-encode strategy
     for strat in ((2, 3) if codec == 2 else (2,)):
         def down_b():
@@ -57,8 +71,9 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
                                                  ctypes.c_void_p(dn.data_ptr()), dn.shape[1], dn.shape[1], sh)
             assert rc == 0
         t = timeit(down_b, 10)
-        print("downsample %-5s batched%s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one launch)" % (
-            name, " strategy %d" % strat if codec == 2 else "", px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch))
+        print("downsample %-5s batched%s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one launch)  %s" % (
+            name, " strategy %d" % strat if codec == 2 else "", px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch,
+            parity("downsample batched %s s%d" % (name, strat), dn[0], T.oracle_downsample(compressor, fmt, b0, n, n, strat))))
     # Pad (helper.h:393-477) to a grid two block rows / columns larger: a copy plus one re-encoded / bit-edited border
     ph = pw = n + 8
     pout = torch.empty((batch, ((ph + 3) // 4) * ((pw + 3) // 4) * bb), dtype=torch.uint8, device=dev)
@@ -68,8 +83,9 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
                                     ctypes.c_void_p(pout[i].data_ptr()), pout.shape[1], sh)
             assert rc == 0
     t = timeit(pad, 5)
-    print("pad %-5s to %d^2 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)" % (
-        name, ph, px / t / 1e6, (blocks.numel() + pout.numel()) / t / 1e9, t * 1e3, batch))
+    print("pad %-5s to %d^2 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)  %s" % (
+        name, ph, px / t / 1e6, (blocks.numel() + pout.numel()) / t / 1e9, t * 1e3, batch,
+        parity("pad " + name, pout[0], T.oracle_pad(compressor, fmt, b0, n, n, ph, pw, 2))))
     sub = torch.empty((batch, per_in // 4), dtype=torch.uint8, device=dev)
     def subimage():
         for i in range(batch):
@@ -77,8 +93,9 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
                                               ctypes.c_void_p(sub[i].data_ptr()), sub.shape[1], sh)
             assert rc == 0
     t = timeit(subimage, 5)
-    print("copy_subimage %-5s %d^2 of %d^2  %6.0f GB/s (%.3f ms per %d images, one call per image)" % (
-        name, n // 2, n, 2 * sub.numel() / t / 1e9, t * 1e3, batch))
+    print("copy_subimage %-5s %d^2 of %d^2  %6.0f GB/s (%.3f ms per %d images, one call per image)  %s" % (
+        name, n // 2, n, 2 * sub.numel() / t / 1e9, t * 1e3, batch,
+        parity("copy_subimage " + name, sub[0], T.oracle_copy_subimage(compressor, fmt, b0, n, n, n // 4, n // 4, n // 2, n // 2))))
     colour = (ctypes.c_uint8 * 4)(200, 100, 50, 255)
     def solid():
         for i in range(batch):
@@ -88,7 +105,9 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         keep = blocks.clone()
     t = timeit(solid, 5) if codec == 2 else None  # (overwrites `blocks`: last use of the ETC1 grid; restored below)
     if t:
-        print("create_solid %-5s %6.0f GB/s written (%.3f ms per %d images of %d^2, one call per image)" % (name, blocks.numel() / t / 1e9, t * 1e3, batch, n))
+        print("create_solid %-5s %6.0f GB/s written (%.3f ms per %d images of %d^2, one call per image)  %s" % (
+            name, blocks.numel() / t / 1e9, t * 1e3, batch, n,
+            parity("create_solid " + name, blocks[0], T.oracle_create_solid(compressor, fmt, n, n, list(colour)))))
         blocks.copy_(keep); del keep
     del pout, sub
     if codec == 0:
@@ -97,7 +116,10 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
             rc = L.icamd_transcode_dxt1_to_etc1_device(ctypes.c_void_p(work.data_ptr()), work.numel(), sh)
             assert rc == 0
         t = timeit(tr, 10)
-        print("transcode dxt1->etc1 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms)" % (px / t / 1e6, 2 * work.numel() / t / 1e9, t * 1e3))
+        work.copy_(blocks)  # (the timed calls transcoded their own output again and again: one clean pass for the check)
+        tr()
+        print("transcode dxt1->etc1 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms)  %s" % (
+            px / t / 1e6, 2 * work.numel() / t / 1e9, t * 1e3, parity("transcode", work[0], T.oracle_transcode(b0))))
     del out, dn, blocks
     torch.cuda.empty_cache()
 
@@ -112,5 +134,8 @@ def dec_pvrtc():
                                ctypes.c_void_p(out.data_ptr()), sh)
     assert rc == 0
 t = timeit(dec_pvrtc)
-print("decode pvrtc %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)" % (
-    batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n))
+print("decode pvrtc %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s (extension: the reference has no PVRTC decoder)" % (
+    batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
+    parity("decode pvrtc", out[0], T.oracle_decode(3, blocks[0].cpu().numpy().tobytes(), n, n).tobytes())))
+print("next rows: %s" % ("ALL LEGS bit-exact vs oracle at the timed shape" if not BAD else "MISMATCH in: " + ", ".join(BAD)))
+sys.exit(1 if BAD else 0)

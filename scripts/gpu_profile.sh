@@ -45,6 +45,15 @@ if [ -z "${SKIP_PRESETS:-}" ]; then
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/preset_$cfg/pmc_write" -o "preset_$cfg" -- $B > "$O/preset_$cfg.write.log" 2>&1
   done
 fi
+# executed VALU instructions of config c4's own launch shape (1 024 x 1024^2 in one launch) per content: the ETC1 search depends
+# on the content AND on the texture size (the smooth ramp is four times steeper at 1024^2) -> valu_insts.json "preset:c4/..."
+if [ -z "${SKIP_PRESETS:-}" ]; then
+  for c in noise smooth flat; do
+    tag=presetsq_c4__${c}
+    rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU --output-format csv -d "$O/$tag/pmc_sq" -o "$tag" -- \
+      python bench.py --steps 5 --warmup 2 --precondition-seconds 0 --config c4 --content $c $COMMON > "$O/$tag.sq.log" 2>&1
+  done
+fi
 # keep the merge small: the raw kernel traces of the preconditioned runs are reduced to per-launch duration lists
 python - <<'PY'
 import csv, glob, os

@@ -28,8 +28,31 @@ def counters(path):
     return {k: sum(v) / len(v) for k, v in agg.items()}
 
 
+def source_version():
+    """The version string the tree's library reports (icamd_version in csrc/ic_capi.hip)."""
+    import re
+    m = re.search(r'icamd_version\(void\)\s*\{\s*return\s*"([^"]+)"', open(os.path.join(ROOT, "image-compression_amd", "csrc", "ic_capi.hip")).read())
+    return m.group(1) if m else None
+
+
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rnd = args[0] if args else "r03"
+    # r05 (VERDICT r04): the tracked evidence must be of the shipped code object -- every profiled bench line carries the
+    # version of the library that ran; a summary of any other build is refused
+    want_version = source_version()
+    stale = []
+    for f in sorted(os.listdir(SRC)) if os.path.isdir(SRC) else []:
+        if f.endswith(".bench.json"):
+            try:
+                got = (json.load(open(os.path.join(SRC, f))).get("library") or {}).get("version")
+            except Exception:
+                got = None
+            if got != want_version:
+                stale.append((f, got))
+    if stale and "--allow-version-mismatch" not in sys.argv:
+        sys.exit("summarize_profiles.py: profiles of another build (tree is %r): %s -- re-run scripts/gpu_profile.sh with the "
+                 "current library" % (want_version, stale))
     os.makedirs(DST, exist_ok=True)
     tpath = os.path.join(DST, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -49,7 +72,7 @@ def main():
             for r in rows:
                 w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
-        summary = {"workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 "
+        summary = {"version": want_version, "workload": wl, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 5 "
                    "--precondition-seconds 0.5 --workload %s --no-cpu-baseline --no-verify --no-host-api --no-sustained "
                    "--no-single-image" % wl, "kernels": {}}
         for r in rows:
@@ -127,6 +150,19 @@ def main():
     for tag in sorted(os.listdir(SRC)):
         d = os.path.join(SRC, tag)
         if not os.path.isdir(d) or tag.startswith("preset_"):
+            continue
+        if tag.startswith("presetsq_"):  # SQ pass of a BASELINE preset's own launch shape: presetsq_c4__<content>
+            cfg, content = tag[len("presetsq_"):].split("__")
+            wl, size, n = shapes[cfg]
+            sq = counters(os.path.join(d, "pmc_sq", tag + "_counter_collection.csv"))
+            insts = sum(v for (k, c), v in sq.items() if c == "SQ_INSTS_VALU")
+            if insts > 0:
+                pm = n * size * size / 1e6
+                valu["preset:%s/%s/s2" % (cfg, content)] = {
+                    "valu_wave_insts_per_Mpixel": insts / pm,
+                    "per_kernel_valu_wave_insts_per_Mpixel": {k: v / pm for (k, c), v in sq.items() if c == "SQ_INSTS_VALU"},
+                    "valu_wave_insts_per_block_lane": round(insts * 64.0 / (pm * 1e6 / 16.0), 1),
+                    "profile": "%s: rocprofv3 --pmc SQ_INSTS_VALU, bench.py --config %s --content %s" % (rnd, cfg, content)}
             continue
         wl, content, strat = (tag.split("__") + ["noise", "s2"])[:3] if "__" in tag else (tag, "noise", "s2")
         sq = counters(os.path.join(d, "pmc_sq", tag + "_counter_collection.csv"))

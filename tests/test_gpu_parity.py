@@ -846,6 +846,12 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
     assert d["configs"]["c5"]["roofline"]["traffic"] and d["roofline"]["traffic"]
     for name, leg in d["slab"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
+        assert leg["distinct_images_rotated"] >= 5 and leg["distinct_source_MiB_per_rank"] >= 320, (name, leg)
+    for name, leg in d["configs"].items():  # r05: every leg says at which clock and VALU issue fraction it ran
+        assert leg["roofline"]["effective_clock_MHz"] > 500 and 0 < leg["roofline"]["valu_frac"] < 1.2, (name, leg["roofline"])
+    other = d["configs"]["c4"]["other_contents"]
+    assert sorted(other) == ["flat", "smooth"] and all(v["parity"].startswith("bit-exact") and v["valu_frac"] for v in other.values())
+    assert d["link_probe"] is None and "value_with_gather_ceiling" in d["scaling_headline"]
     d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--shard", "slab", "--workload", "dxt5_rgba8",
                     "--size", "8192", "--steps", "3"])
     assert d["scaling"] == "strong" and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
@@ -855,6 +861,41 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
     if torch.cuda.device_count() < 2:
         d = _run_bench(["--gpus", "2", "--backend", "gloo", "--shard", "slab", "--workload", "dxt1_rgb888", "--size", "2052", "--steps", "3"])
         assert d["n_gpus"] == 2 and d["slab_block_rows"] == [256, 257] and d["parity"].startswith("bit-exact") and d["value_with_gather"] > 0
+
+
+def test_bench_rehearsal_of_the_drivers_eight_rank_command(pkg):
+    """The driver's first 8-GPU SCALE run is one shot, so its exact command is rehearsed here: `bench.py --gpus 8` (default
+    line: c2 + configs {c3, c4, c5} + slab legs, every leg with its gather).  With fewer than 8 GPUs the eight ranks share
+    the box's GPU(s) over gloo (collectives staged through the host): every split, count, buffer shape, barrier and parity
+    check of the 8-rank run executes; only the transport differs from RCCL."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    d = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--extra-steps", "2", "--precondition-seconds", "0",
+                    "--backend", backend], timeout=1500)
+    assert d["n_gpus"] == 8 and d["config"]["world_size"] == 8 and d["scaling"] == "weak"
+    assert d["parity"].startswith("bit-exact") and d["config"]["textures_per_step_all_gpus"] == 8 * 16
+    assert d["value"] > 0 and d["value_with_gather"] > 0 and d["rank0_copy_matches"] is True
+    assert d["gather_ranks"] == 8 and d["gather_bound_GBps"] > 0 and d["value_with_gather_ceiling"] > 0
+    assert d["gather_bytes_into_rank0_per_step"] == 7 * 16 * 4096 * 4096 // 2
+    lp = d["link_probe"]
+    assert lp["peers"] == 7 and len(lp["per_peer_alone_GBps"]) == 7 and lp["payload_intact"] and lp["xgmi_links_into_rank0"] == 7
+    assert "value_with_gather_ceiling" in d["scaling_headline"]
+    assert sorted(d["configs"]) == ["c3", "c4", "c5"]
+    for name, leg in d["configs"].items():
+        assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
+        assert leg["rank0_copy_matches"] is True and leg["gather_ranks"] == 8 and leg["gather_bound_GBps"] > 0, (name, leg)
+    c4 = d["configs"]["c4"]  # 1 024 textures over 8 ranks by texture_range: 128 each, strong scaling
+    assert c4["textures_per_gpu_per_step"] == 128 and c4["scaling"] == "strong"
+    assert sorted(c4["other_contents"]) == ["flat", "smooth"]
+    for content, leg in c4["other_contents"].items():
+        assert leg["parity"].startswith("bit-exact") and leg["value"] > 0, (content, leg)
+    assert d["configs"]["c3"]["scaling"] == "weak" and d["configs"]["c5"]["textures_per_gpu_per_step"] == 16
+    for name, size in (("c2_one_4096", 4096), ("c3_one_8192", 8192), ("one_16384", 16384)):
+        leg = d["slab"][name]
+        assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
+        assert leg["slab_block_rows"] == [size // 4 // 8] * 8 and leg["scaling"] == "strong" and leg["gather_ranks"] == 8
+        # every rank's slabs are read from HBM, not from the 256 MiB Infinity Cache
+        assert leg["distinct_images_rotated"] >= 5 and leg["distinct_source_MiB_per_rank"] >= 320, (name, leg)
 
 
 def test_rccl_code_path_executes_with_a_single_rank(pkg):

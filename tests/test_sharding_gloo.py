@@ -38,7 +38,7 @@ def _worker(rank, world, port, results):
     ok = True
     # (1) batch of independent textures, ETC1 (config 4 shape in miniature) + PVRTC
     for codec, comps, size in ((T.ETC1, 3, 32), (T.PVRTC2, 4, 32), (T.DXT1, 4, 20)):
-        n = 6
+        n = 6 if 6 % world == 0 else 2 * world  # equal per-rank counts for the one-collective gather
         batch = np.stack([T.s_mixed(size, size, comps, index=i) for i in range(n)])
 
         def enc(t):
@@ -111,7 +111,7 @@ def _worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])  # 3: unequal texture counts and slab heights on the ranks
+@pytest.mark.parametrize("world", [2, 3, 8])  # 3: unequal texture counts and slab heights on the ranks; 8: the driver's N
 def test_sharded_encode_and_gather(world):
     port = _free_port()
     with mp.Manager() as mgr:
@@ -193,10 +193,16 @@ def _slab_worker(rank, world, port, results):
     sh = _load_sharding()
     ctx = bench.Ctx(torch, dist, rank, world, torch.device("cpu"), True, "gloo")
     ok = True
+    # what the line says about the gather (r05): measured inbound rate of rank 0 -> gather_bound_GBps / ceiling in every leg
+    probe = bench.link_probe(ctx, mib=1, reps=1)
+    ok &= probe["peers"] == world - 1 and len(probe["per_peer_alone_GBps"]) == world - 1 and probe["payload_intact"] \
+        and probe["all_peers_at_once_GBps_into_rank0"] > 0 and probe["xgmi_links_into_rank0"] == min(world - 1, 7)
     for workload, size, content in (("dxt1_rgba8", 64, "noise"), ("dxt5_rgba8", 40, "smooth"), ("dxt1_rgb888", 12, "flat")):
-        res = bench.slab_leg(ctx, _OraclePkg, sh, workload, size, 2, content)
+        res = bench.slab_leg(ctx, _OraclePkg, sh, workload, size, 2, content, probe=probe, rotate_max=6)
         good = res["parity"].startswith("bit-exact") and res.get("value_with_gather") is not None and res["scaling"] == "strong" \
-            and sum(res["slab_block_rows"]) == (size + 3) // 4
+            and sum(res["slab_block_rows"]) == (size + 3) // 4 and res["distinct_images_rotated"] == 6 \
+            and res["gather_ranks"] == world and res["gather_bound_GBps"] == probe["all_peers_at_once_GBps_into_rank0"] \
+            and res["value_with_gather_ceiling"] > 0
         if not good:
             print("slab_leg failed on rank %d: %r" % (rank, res), file=sys.stderr, flush=True)
         ok &= good
@@ -208,7 +214,7 @@ def _slab_worker(rank, world, port, results):
             if rank == world - 1:
                 out.view(-1)[0] ^= 1
             return out
-    res = bench.slab_leg(ctx, Bad, sh, "dxt1_rgba8", 64, 1, "noise")
+    res = bench.slab_leg(ctx, Bad, sh, "dxt1_rgba8", 64, 1, "noise", rotate_max=5)
     ok &= res["parity"].startswith("MISMATCH")
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -216,7 +222,7 @@ def _slab_worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])  # 3: unequal slab heights -> the batched isend / irecv gather
+@pytest.mark.parametrize("world", [2, 3, 8])  # 3: unequal slab heights -> the batched isend / irecv gather; 8: the driver's N
 def test_bench_slab_mode_over_gloo(world):
     port = _free_port()
     with mp.Manager() as mgr:
