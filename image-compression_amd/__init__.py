@@ -36,7 +36,7 @@ EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_downsample_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
+    "icamd_downsample", "icamd_downsample_batch_device", "icamd_pad_batch_device", "icamd_create_solid_batch_device", "icamd_copy_subimage_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
     "icamd_pvrtc2_set_workspace", "icamd_pvrtc2_tune", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
@@ -117,6 +117,14 @@ def lib():
             L.icamd_host_unregister.argtypes = [_vp]
             L.icamd_pvrtc2_decompress.restype = _ci
             L.icamd_pvrtc2_decompress.argtypes = [_u32, _vp, _sz, _vp, _sz]
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_pad_batch_device"):  # r05 entry points
+            L.icamd_pad_batch_device.restype = _ci
+            L.icamd_pad_batch_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _sz, _u32, _u32, _vp, _sz, _sz, _vp]
+            L.icamd_create_solid_batch_device.restype = _ci
+            L.icamd_create_solid_batch_device.argtypes = [_ci, _ci, _u32, _u32, _u32, _vp, _vp, _sz, _sz, _vp]
+            L.icamd_copy_subimage_batch_device.restype = _ci
+            L.icamd_copy_subimage_batch_device.argtypes = [_ci, _ci, _u32, _u32, _u32, _vp, _sz, _u32, _u32, _u32, _u32, _vp, _sz,
+                                                           _sz, _vp]
         if not LIB_OVERRIDDEN or hasattr(L, "icamd_create_solid_device"):  # r03 entry points
             L.icamd_create_solid_device.restype = _ci
             L.icamd_create_solid_device.argtypes = [_ci, _ci, _u32, _u32, _vp, _vp, _sz, _vp]
@@ -297,7 +305,12 @@ def downsample_device(compressor, fmt, blocks, height, width, *, etc_strategy=ET
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
     dh, dw = (height + 1) // 2, (width + 1) // 2
     per_out = ((dh + 3) // 4) * ((dw + 3) // 4) * _block_bytes(compressor, fmt)
+    if n_images < 1 or blocks.numel() % n_images:
+        raise ValueError("downsample_device: %d bytes do not divide into %d images" % (blocks.numel(), n_images))
     per_in = blocks.numel() // n_images
+    need = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    if per_in < need:  # the kernel's 16-byte block loads would run past the tensor
+        raise ValueError("downsample_device: %d bytes per image, a %d x %d image has %d" % (per_in, height, width, need))
     out = torch.empty((n_images, per_out), dtype=torch.uint8, device=blocks.device)
     st = lib().icamd_downsample_batch_device(compressor, etc_strategy, fmt, height, width, n_images,
                                              ctypes.c_void_p(blocks.data_ptr()), per_in, ctypes.c_void_p(out.data_ptr()),
@@ -394,6 +407,43 @@ def create_solid_device(compressor, fmt, height, width, color, *, device=None, o
     st = lib().icamd_create_solid_device(compressor, fmt, height, width, buf, ctypes.c_void_p(out.data_ptr()), n,
                                          _stream_handle(stream))
     return out[:n] if _check(st, "icamd_create_solid_device") else None
+
+
+def create_solid_batch_device(compressor, fmt, height, width, colors, *, device=None, stream=None):
+    """icamd_create_solid_batch_device (extension): len(colors) solid images in one launch -> [n, bytes] device tensor."""
+    comps = 3 if fmt in (RGB, BGR) else 4
+    flat = bytes(bytearray(b for c in colors for b in bytearray(c)[:comps]))
+    buf = (ctypes.c_uint8 * max(len(flat), 4))(*flat)
+    per = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = torch.empty((len(colors), max(per, 1)), dtype=torch.uint8, device=device or torch.device("cuda", torch.cuda.current_device()))
+    st = lib().icamd_create_solid_batch_device(compressor, fmt, height, width, len(colors), buf, ctypes.c_void_p(out.data_ptr()),
+                                               out.shape[1], per, _stream_handle(stream))
+    return out[:, :per] if _check(st, "icamd_create_solid_batch_device") else None
+
+
+def pad_batch_device(compressor, fmt, blocks, compressed_height, compressed_width, padded_height, padded_width, *,
+                     etc_strategy=ETC_SMALLER_ERROR, stream=None):
+    """icamd_pad_batch_device (extension): blocks = [n, bytes] device tensor of equally shaped grids -> [n, bytes] padded."""
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous() and blocks.dim() == 2
+    per = ((padded_height + 3) // 4) * ((padded_width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = torch.empty((blocks.shape[0], max(per, 1)), dtype=torch.uint8, device=blocks.device)
+    st = lib().icamd_pad_batch_device(compressor, etc_strategy, fmt, compressed_height, compressed_width, blocks.shape[0],
+                                      ctypes.c_void_p(blocks.data_ptr()), blocks.shape[1], padded_height, padded_width,
+                                      ctypes.c_void_p(out.data_ptr()), out.shape[1], per, _stream_handle(stream))
+    return out[:, :per] if _check(st, "icamd_pad_batch_device") else None
+
+
+def copy_subimage_batch_device(compressor, fmt, blocks, compressed_height, compressed_width, start_row, start_column, height,
+                               width, *, stream=None):
+    """icamd_copy_subimage_batch_device (extension): the same window of every grid of blocks = [n, bytes]."""
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous() and blocks.dim() == 2
+    per = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    out = torch.empty((blocks.shape[0], max(per, 1)), dtype=torch.uint8, device=blocks.device)
+    st = lib().icamd_copy_subimage_batch_device(compressor, fmt, compressed_height, compressed_width, blocks.shape[0],
+                                                ctypes.c_void_p(blocks.data_ptr()), blocks.shape[1], start_row, start_column,
+                                                height, width, ctypes.c_void_p(out.data_ptr()), out.shape[1], per,
+                                                _stream_handle(stream))
+    return out[:, :per] if _check(st, "icamd_copy_subimage_batch_device") else None
 
 
 def create_solid_host(compressor, fmt, height, width, color):

@@ -12,10 +12,11 @@ constexpr int kWords(int codec) { return codec == ICAMD_DXT5 ? 4 : 2; }
 
 // (r, c) of output block k: the source block it copies / replicates, and whether it is a pad block.
 template <int CODEC, int STRATEGY>
-__device__ __forceinline__ void pad_block(const BlockOpParams &P, uint32_t r, uint32_t c, bool copy_interior, bool make_border) {
+__device__ __forceinline__ void pad_block(const BlockOpParams &P, uint32_t img, uint32_t r, uint32_t c, bool copy_interior,
+                                          bool make_border) {
   constexpr int W = kWords(CODEC);
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src);
-  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst) + ((size_t)r * P.out_cols + c) * W;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src + (size_t)img * P.src_image_stride);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst + (size_t)img * P.dst_image_stride) + ((size_t)r * P.out_cols + c) * W;
   const bool in_rows = r < P.in_rows, in_cols = c < P.in_cols;
   if (in_rows && in_cols ? !copy_interior : !make_border) return;
   const uint32_t sr = in_rows ? r : P.in_rows - 1, sc = in_cols ? c : P.in_cols - 1;
@@ -50,18 +51,25 @@ __device__ __forceinline__ void pad_block(const BlockOpParams &P, uint32_t r, ui
 // 8 waves per SIMD) and the pad blocks as a second, small launch over the BORDER only (PART 2: the in_rows x extra columns to
 // the right, then the extra rows over the full width); in one kernel the searches' 121 VGPRs capped the copy at 4 waves per SIMD
 // and every wave that touched the border ran the search (28.6 -> ~7 us per 4096^2 image padded by 8 pixels).
+// Batched launches (icamd_pad_batch_device, r05): n_images equally shaped grids, out_per_image work items each (output blocks;
+// PART 2: border blocks).
 template <int CODEC, int STRATEGY, int PART>
 __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
+  uint32_t img = 0;
+  if (P.n_images > 1) {
+    img = fastdiv(k, P.div_out_per_image);
+    k -= img * P.out_per_image;
+  }
   if (PART == 2) {
     const uint32_t dc = P.out_cols - P.in_cols, right = P.in_rows * dc;
     uint32_t r, c;
     if (k < right) { r = k / dc; c = P.in_cols + (k - r * dc); }
     else { const uint32_t j = k - right; r = P.in_rows + j / P.out_cols; c = j - (r - P.in_rows) * P.out_cols; }
-    pad_block<CODEC, STRATEGY>(P, r, c, false, true);
+    pad_block<CODEC, STRATEGY>(P, img, r, c, false, true);
     return;
   }
   const uint32_t r = fastdiv(k, P.div_out_cols), c = k - r * P.out_cols;
-  pad_block<CODEC, STRATEGY>(P, r, c, true, PART == 0);
+  pad_block<CODEC, STRATEGY>(P, img, r, c, true, PART == 0);
 }
 
 // STRATEGY: the ETC1 re-encode strategy as a compile-time constant (one kernel per strategy, like the encoders: the
@@ -193,7 +201,9 @@ hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
     hipLaunchKernelGGL(icamd_pad_etc1_copy_kernel, grid, block, 0, stream, P);
     BlockOpParams B = P;  // the pad blocks only: right of the image, then below it
     const uint64_t border = (uint64_t)P.in_rows * (P.out_cols - P.in_cols) + (uint64_t)(P.out_rows - P.in_rows) * P.out_cols;
-    B.total_out = (uint32_t)border;
+    B.out_per_image = (uint32_t)border;
+    B.div_out_per_image = make_fastdiv(border ? (uint32_t)border : 1u);
+    B.total_out = (uint32_t)(border * P.n_images);
     if (border) {
       const dim3 bgrid((B.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup);
       if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_h_kernel, bgrid, block, 0, stream, B);
@@ -236,6 +246,24 @@ struct FillParams {
   uint32_t w[4];
   uint32_t words;  // 2 or 4
 };
+// n <= kFillBatch images of blocks_per_image blocks each, image i filled with its own block w[i] (icamd_create_solid_batch_device)
+constexpr uint32_t kFillBatch = 64;
+struct FillBatchParams {
+  uint8_t *dst;
+  uint64_t dst_image_stride;
+  uint32_t blocks_per_image, words, n;
+  uint32_t w[kFillBatch][4];
+};
+extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_fill_blocks_batch_kernel(FillBatchParams P) {
+  const uint32_t img = blockIdx.y;
+  uint8_t *dst = P.dst + (size_t)img * P.dst_image_stride;
+  const uint32_t w0 = P.w[img][0], w1 = P.w[img][1], w2 = P.w[img][2], w3 = P.w[img][3];
+  const uint32_t stride = gridDim.x * kThreadsPerWorkgroup;
+  for (uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x; k < P.blocks_per_image; k += stride) {
+    if (P.words == 4) store_stream16(dst + (size_t)k * 16u, w0, w1, w2, w3);
+    else store_stream8(dst + (size_t)k * 8u, w0, w1);
+  }
+}
 extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_fill_blocks_kernel(FillParams P) {
   const uint64_t stride = (uint64_t)gridDim.x * kThreadsPerWorkgroup;
   for (uint64_t k = (uint64_t)blockIdx.x * kThreadsPerWorkgroup + threadIdx.x; k < P.n_blocks; k += stride) {
@@ -250,11 +278,13 @@ struct SubimageParams {
   const uint8_t *src;
   uint8_t *dst;
   uint32_t src_cols, r0, c0, rows, cols, words, row_first;
+  uint64_t src_image_stride, dst_image_stride;  // blockIdx.z = image (icamd_copy_subimage_batch_device)
 };
 extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_copy_subimage_kernel(SubimageParams P) {
   const uint32_t c = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x, r = P.row_first + blockIdx.y;
   if (c >= P.cols) return;
-  const size_t so = ((size_t)(P.r0 + r) * P.src_cols + P.c0 + c) * (P.words * 4u), dof = ((size_t)r * P.cols + c) * (P.words * 4u);
+  const size_t so = (size_t)blockIdx.z * P.src_image_stride + ((size_t)(P.r0 + r) * P.src_cols + P.c0 + c) * (P.words * 4u);
+  const size_t dof = (size_t)blockIdx.z * P.dst_image_stride + ((size_t)r * P.cols + c) * (P.words * 4u);
   if (P.words == 4) {
     const U4 v = *reinterpret_cast<const U4 *>(P.src + so);
     store_stream16(P.dst + dof, v.x, v.y, v.z, v.w);
@@ -278,20 +308,49 @@ hipError_t launch_fill_blocks(void *dst, uint64_t n_blocks, int block_bytes, con
   return hipGetLastError();
 }
 
+hipError_t launch_fill_blocks_batch(void *dst, uint64_t dst_image_stride, uint32_t blocks_per_image, int block_bytes,
+                                    const uint32_t (*words)[4], uint32_t n_images, hipStream_t stream) {
+  if (blocks_per_image == 0 || n_images == 0) return hipSuccess;
+  (void)hipGetLastError();
+  uint32_t wgs = (blocks_per_image + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup;
+  for (uint32_t first = 0; first < n_images; first += kFillBatch) {
+    FillBatchParams P;
+    P.n = n_images - first < kFillBatch ? n_images - first : kFillBatch;
+    P.dst = static_cast<uint8_t *>(dst) + (uint64_t)first * dst_image_stride;
+    P.dst_image_stride = dst_image_stride;
+    P.blocks_per_image = blocks_per_image;
+    P.words = (uint32_t)block_bytes / 4u;
+    for (uint32_t i = 0; i < P.n; ++i)
+      for (int j = 0; j < 4; ++j) P.w[i][j] = words[first + i][j];
+    // ~8 waves on every SIMD over the whole launch; the loop covers the rest of an image
+    const uint32_t per_image = (256u * 32u + P.n - 1) / P.n;
+    hipLaunchKernelGGL(icamd_fill_blocks_batch_kernel, dim3(wgs < per_image ? wgs : per_image, P.n), dim3(kThreadsPerWorkgroup), 0, stream, P);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_copy_subimage(int block_bytes, const void *src, uint32_t src_cols, uint32_t r0, uint32_t c0,
-                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream) {
-  if (rows == 0 || cols == 0) return hipSuccess;
+                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream, uint32_t n_images,
+                                uint64_t src_image_stride, uint64_t dst_image_stride) {
+  if (rows == 0 || cols == 0 || n_images == 0) return hipSuccess;
   SubimageParams P;
   P.src = static_cast<const uint8_t *>(src);
   P.dst = static_cast<uint8_t *>(dst);
   P.src_cols = src_cols; P.r0 = r0; P.c0 = c0; P.rows = rows; P.cols = cols;
   P.words = (uint32_t)block_bytes / 4u;
+  P.src_image_stride = src_image_stride;
+  P.dst_image_stride = dst_image_stride;
   (void)hipGetLastError();
   const uint32_t gx = (cols + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup;
-  for (uint32_t first = 0; first < rows; first += 65535u) {
-    P.row_first = first;
-    hipLaunchKernelGGL(icamd_copy_subimage_kernel, dim3(gx, rows - first < 65535u ? rows - first : 65535u),
-                       dim3(kThreadsPerWorkgroup), 0, stream, P);
+  for (uint32_t img0 = 0; img0 < n_images; img0 += 65535u) {
+    const uint32_t nz = n_images - img0 < 65535u ? n_images - img0 : 65535u;
+    P.src = static_cast<const uint8_t *>(src) + (uint64_t)img0 * src_image_stride;
+    P.dst = static_cast<uint8_t *>(dst) + (uint64_t)img0 * dst_image_stride;
+    for (uint32_t first = 0; first < rows; first += 65535u) {
+      P.row_first = first;
+      hipLaunchKernelGGL(icamd_copy_subimage_kernel, dim3(gx, rows - first < 65535u ? rows - first : 65535u, nz),
+                         dim3(kThreadsPerWorkgroup), 0, stream, P);
+    }
   }
   return hipGetLastError();
 }

@@ -647,29 +647,48 @@ int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_
 
 // ---- compressed-domain operations
 
-int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const void *d_blocks,
-                     uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) {
+int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, uint32_t n_images,
+                           const void *d_blocks, size_t src_image_stride_bytes, uint32_t ph, uint32_t pw, void *d_out,
+                           size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
   int codec;
   if (!d_blocks || !d_out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
-  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
-    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
   icamd::BlockOpParams P;
   P.in_rows = num_blocks4(ch); P.in_cols = num_blocks4(cw);
   P.out_rows = num_blocks4(ph); P.out_cols = num_blocks4(pw);
   if (P.in_rows == 0 || P.in_cols == 0 || P.out_rows < P.in_rows || P.out_cols < P.in_cols) return ICAMD_FALSE;
-  if (out_size != icamd_encoded_size(codec, ph, pw)) return ICAMD_FALSE;
+  if (out_size_per_image != icamd_encoded_size(codec, ph, pw)) return ICAMD_FALSE;
+  if (n_images > 1 && (src_image_stride_bytes < icamd_encoded_size(codec, ch, cw) || dst_image_stride_bytes < out_size_per_image))
+    return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
+  if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
-  P.src = static_cast<const uint8_t *>(d_blocks);
-  P.dst = static_cast<uint8_t *>(d_out);
-  const uint64_t total = (uint64_t)P.out_rows * P.out_cols;
-  if (total >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one launch");
-  P.total_out = (uint32_t)total;
+  const uint64_t per = (uint64_t)P.out_rows * P.out_cols;
+  if (per >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "more than 2^31 blocks in one image");
   P.etc_strategy = (uint32_t)etc_strategy;
   P.src_height = ch; P.src_width = cw;
   P.div_out_cols = icamd::make_fastdiv(P.out_cols);
-  ICAMD_HIP(icamd::launch_pad(codec, P, static_cast<hipStream_t>(hip_stream)), "launch pad");
+  P.out_per_image = (uint32_t)per;
+  P.div_out_per_image = icamd::make_fastdiv(P.out_per_image);
+  P.src_image_stride = src_image_stride_bytes;
+  P.dst_image_stride = dst_image_stride_bytes;
+  // as many images per launch as the 32-bit block index allows
+  const uint64_t group = std::max<uint64_t>(1, ((1ull << 31) - 1) / per);
+  for (uint64_t first = 0; first < n_images; first += group) {
+    const uint64_t count = std::min<uint64_t>(group, n_images - first);
+    P.src = static_cast<const uint8_t *>(d_blocks) + first * src_image_stride_bytes;
+    P.dst = static_cast<uint8_t *>(d_out) + first * dst_image_stride_bytes;
+    P.n_images = (uint32_t)count;
+    P.total_out = (uint32_t)(per * count);
+    ICAMD_HIP(icamd::launch_pad(codec, P, static_cast<hipStream_t>(hip_stream)), "launch pad");
+  }
   return ICAMD_OK;
+}
+
+int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const void *d_blocks,
+                     uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) {
+  return icamd_pad_batch_device(compressor, etc_strategy, format, ch, cw, 1, d_blocks, 0, ph, pw, d_out, 0, out_size, hip_stream);
 }
 
 int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, uint32_t n_images,
@@ -677,7 +696,6 @@ int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, 
                                   size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
   int codec;
   if (!d_blocks || !d_out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
-  if (n_images == 0) return ICAMD_OK;
   if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
     return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
   icamd::BlockOpParams P;
@@ -688,8 +706,12 @@ int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, 
   const uint32_t dh = (uh + 1) / 2, dw = (uw + 1) / 2;
   P.out_rows = num_blocks4(dh); P.out_cols = num_blocks4(dw);
   if (out_size_per_image != icamd_encoded_size(codec, dh, dw)) return ICAMD_FALSE;
-  if (n_images > 1 && (src_image_stride_bytes < icamd_encoded_size(codec, uh, uw) || dst_image_stride_bytes < out_size_per_image))
-    return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
+  // (a non-zero stride is checked for one image too: a caller that passes one states how far its buffer reaches)
+  if ((n_images > 1 || src_image_stride_bytes != 0) && src_image_stride_bytes < icamd_encoded_size(codec, uh, uw))
+    return fail(ICAMD_ERR_ARG, "source image stride smaller than an image");
+  if ((n_images > 1 || dst_image_stride_bytes != 0) && dst_image_stride_bytes < out_size_per_image)
+    return fail(ICAMD_ERR_ARG, "destination image stride smaller than an image");
+  if (n_images == 0) return ICAMD_OK;  // (after the checks: a call the reference would refuse is refused for any count)
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   const uint64_t per = (uint64_t)P.out_rows * P.out_cols;
@@ -856,6 +878,30 @@ bool subimage_geometry(int compressor, int format, uint32_t ch, uint32_t cw, uin
 }
 }  // namespace
 
+int icamd_create_solid_batch_device(int compressor, int format, uint32_t height, uint32_t width, uint32_t n_images,
+                                    const uint8_t *colors, void *d_out, size_t dst_image_stride_bytes, size_t out_size_per_image,
+                                    void *hip_stream) {
+  const int comps = format_components(format);
+  uint32_t probe[4];
+  if (!colors || !d_out || comps == 0) return ICAMD_FALSE;
+  const uint32_t bb = solid_block(compressor, format, colors, probe);
+  if (bb == 0) return ICAMD_FALSE;
+  const uint64_t n = (uint64_t)num_blocks4(height) * num_blocks4(width);
+  if (out_size_per_image != n * bb) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
+  if ((reinterpret_cast<uintptr_t>(d_out) | dst_image_stride_bytes) % 4u) return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
+  if (n_images > 1 && dst_image_stride_bytes < out_size_per_image) return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
+  if (n >= (1ull << 32)) return fail(ICAMD_ERR_ARG, "more than 2^32 blocks in one image");
+  if (n_images == 0) return ICAMD_OK;
+  int rc = require_device();
+  if (rc != ICAMD_OK) return rc;
+  std::vector<uint32_t> words((size_t)n_images * 4u);
+  for (uint32_t i = 0; i < n_images; ++i) (void)solid_block(compressor, format, colors + (size_t)i * (size_t)comps, &words[(size_t)i * 4u]);
+  ICAMD_HIP(icamd::launch_fill_blocks_batch(d_out, dst_image_stride_bytes, (uint32_t)n, (int)bb,
+                                            reinterpret_cast<const uint32_t (*)[4]>(words.data()), n_images,
+                                            static_cast<hipStream_t>(hip_stream)), "launch fill");
+  return ICAMD_OK;
+}
+
 int icamd_create_solid_device(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color,
                               void *d_out, size_t out_size, void *hip_stream) {
   uint32_t w[4];
@@ -883,22 +929,35 @@ int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t wid
   return ICAMD_OK;
 }
 
-int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
-                               const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
-                               uint32_t width, void *d_out, size_t out_size, void *hip_stream) {
+int icamd_copy_subimage_batch_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                                     uint32_t n_images, const void *d_blocks, size_t src_image_stride_bytes, uint32_t start_row,
+                                     uint32_t start_column, uint32_t height, uint32_t width, void *d_out,
+                                     size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
   int bb;
   if (!d_blocks || !d_out ||
       !subimage_geometry(compressor, format, compressed_height, compressed_width, start_row, start_column, height, width, &bb))
     return ICAMD_FALSE;
   const uint32_t rows = num_blocks4(height), cols = num_blocks4(width);
-  if (out_size != (size_t)rows * cols * (size_t)bb) return ICAMD_FALSE;
-  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out)) % 4u)
-    return fail(ICAMD_ERR_ARG, "block pointers must be 4-byte aligned");
+  if (out_size_per_image != (size_t)rows * cols * (size_t)bb) return ICAMD_FALSE;
+  if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
+    return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
+  if (n_images > 1 && (src_image_stride_bytes < (size_t)num_blocks4(compressed_height) * num_blocks4(compressed_width) * (size_t)bb ||
+                       dst_image_stride_bytes < out_size_per_image))
+    return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
+  if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   ICAMD_HIP(icamd::launch_copy_subimage(bb, d_blocks, num_blocks4(compressed_width), start_row / 4u, start_column / 4u,
-                                        rows, cols, d_out, static_cast<hipStream_t>(hip_stream)), "launch copy_subimage");
+                                        rows, cols, d_out, static_cast<hipStream_t>(hip_stream), n_images,
+                                        src_image_stride_bytes, dst_image_stride_bytes), "launch copy_subimage");
   return ICAMD_OK;
+}
+
+int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                               const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
+                               uint32_t width, void *d_out, size_t out_size, void *hip_stream) {
+  return icamd_copy_subimage_batch_device(compressor, format, compressed_height, compressed_width, 1, d_blocks, 0, start_row,
+                                          start_column, height, width, d_out, 0, out_size, hip_stream);
 }
 
 // Host form: block-row memcpys like the reference (helper.h:583-589); nothing to offload.

@@ -102,7 +102,7 @@ struct BlockOpParams {
   uint32_t etc_strategy;
   uint32_t src_height, src_width;  // uncompressed pixels of the source (Downsample's single-block case)
   FastDiv div_out_cols;
-  // Downsample only: n_images equally shaped block grids per launch (total_out = out_rows * out_cols * n_images)
+  // Downsample / Pad: n_images equally shaped block grids per launch (total_out = out_rows * out_cols * n_images)
   uint32_t n_images = 1, out_per_image = 0;
   uint64_t src_image_stride = 0, dst_image_stride = 0;  // bytes
   FastDiv div_out_per_image = { 0, 0, 1 };
@@ -114,7 +114,11 @@ hipError_t launch_transcode_dxt1_to_etc1(void *blocks, uint32_t n_blocks, hipStr
 // starting at block (r0, c0) of a grid src_cols blocks wide.
 hipError_t launch_fill_blocks(void *dst, uint64_t n_blocks, int block_bytes, const uint32_t words[4], hipStream_t stream);
 hipError_t launch_copy_subimage(int block_bytes, const void *src, uint32_t src_cols, uint32_t r0, uint32_t c0,
-                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream);
+                                uint32_t rows, uint32_t cols, void *dst, hipStream_t stream, uint32_t n_images = 1,
+                                uint64_t src_image_stride = 0, uint64_t dst_image_stride = 0);
+// n_images grids of blocks_per_image blocks, dst_image_stride bytes apart, image i filled with words[i]
+hipError_t launch_fill_blocks_batch(void *dst, uint64_t dst_image_stride, uint32_t blocks_per_image, int block_bytes,
+                                    const uint32_t (*words)[4], uint32_t n_images, hipStream_t stream);
 // Diagnostics: one wave spins for `ticks` periods of the constant-rate clock (s_memrealtime) and records how many shader
 // cycles (s_memtime) passed meanwhile: d_out[0] = shader cycles, d_out[1] = constant-rate ticks.
 hipError_t launch_clock_probe(uint64_t *d_out, uint64_t ticks, hipStream_t stream);

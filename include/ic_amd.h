@@ -183,6 +183,13 @@ int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_
 int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
                      const void *d_blocks, uint32_t padded_height, uint32_t padded_width, void *d_out, size_t out_size,
                      void *hip_stream);
+/* Extension (r05), like icamd_downsample_batch_device: n_images equally shaped grids padded in ONE launch (two for ETC1: the
+ * copy, then every image's border blocks together -- a single image's ETC1 border is a few thousand dependent searches on an
+ * otherwise empty chip).  Image i at d_blocks + i * src_image_stride_bytes -> d_out + i * dst_image_stride_bytes (multiples of 4). */
+int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
+                           uint32_t n_images, const void *d_blocks, size_t src_image_stride_bytes, uint32_t padded_height,
+                           uint32_t padded_width, void *d_out, size_t dst_image_stride_bytes, size_t out_size_per_image,
+                           void *hip_stream);
 int icamd_pad(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
               const uint8_t *blocks, uint32_t padded_height, uint32_t padded_width, uint8_t *out, size_t out_size);
 
@@ -210,6 +217,11 @@ int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t unco
  * (byte shuffling: nothing to offload). */
 int icamd_create_solid_device(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color,
                               void *d_out, size_t out_size, void *hip_stream);
+/* Extension (r05): n_images grids in ONE launch, image i of colour colors[i * components .. ] (HOST pointer, n_images x 3 or 4
+ * bytes) at d_out + i * dst_image_stride_bytes.  A 4096^2 DXT1 grid is 8 MiB: one fill per call is launch-bound. */
+int icamd_create_solid_batch_device(int compressor, int format, uint32_t height, uint32_t width, uint32_t n_images,
+                                    const uint8_t *colors, void *d_out, size_t dst_image_stride_bytes, size_t out_size_per_image,
+                                    void *hip_stream);
 int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color, uint8_t *out,
                        size_t out_size);
 
@@ -220,6 +232,11 @@ int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t wid
 int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
                                const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
                                uint32_t width, void *d_out, size_t out_size, void *hip_stream);
+/* Extension (r05): the same window of n_images equally shaped grids in ONE launch (strides multiples of 4). */
+int icamd_copy_subimage_batch_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
+                                     uint32_t n_images, const void *d_blocks, size_t src_image_stride_bytes, uint32_t start_row,
+                                     uint32_t start_column, uint32_t height, uint32_t width, void *d_out,
+                                     size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream);
 int icamd_copy_subimage(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
                         const uint8_t *blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
                         uint32_t width, uint8_t *out, size_t out_size);

@@ -86,6 +86,15 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
     print("pad %-5s to %d^2 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d images, one call per image)  %s" % (
         name, ph, px / t / 1e6, (blocks.numel() + pout.numel()) / t / 1e9, t * 1e3, batch,
         parity("pad " + name, pout[0], T.oracle_pad(compressor, fmt, b0, n, n, ph, pw, 2))))
+    def pad_b():
+        rc = L.icamd_pad_batch_device(compressor, 2, fmt, n, n, batch, ctypes.c_void_p(blocks.data_ptr()), per_in, ph, pw,
+                                      ctypes.c_void_p(pout.data_ptr()), pout.shape[1], pout.shape[1], sh)
+        assert rc == 0
+    pout.zero_()
+    t = timeit(pad_b, 10)
+    print("pad %-5s to %d^2 batched %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d images, one call)  %s" % (
+        name, ph, px / t / 1e6, (blocks.numel() + pout.numel()) / t / 1e9, t * 1e3, batch,
+        parity("pad batched " + name, pout[batch - 1], T.oracle_pad(compressor, fmt, blocks[batch - 1].cpu().numpy().tobytes(), n, n, ph, pw, 2))))
     sub = torch.empty((batch, per_in // 4), dtype=torch.uint8, device=dev)
     def subimage():
         for i in range(batch):
@@ -96,6 +105,15 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
     print("copy_subimage %-5s %d^2 of %d^2  %6.0f GB/s (%.3f ms per %d images, one call per image)  %s" % (
         name, n // 2, n, 2 * sub.numel() / t / 1e9, t * 1e3, batch,
         parity("copy_subimage " + name, sub[0], T.oracle_copy_subimage(compressor, fmt, b0, n, n, n // 4, n // 4, n // 2, n // 2))))
+    def subimage_b():
+        rc = L.icamd_copy_subimage_batch_device(compressor, fmt, n, n, batch, ctypes.c_void_p(blocks.data_ptr()), per_in, n // 4, n // 4,
+                                                n // 2, n // 2, ctypes.c_void_p(sub.data_ptr()), sub.shape[1], sub.shape[1], sh)
+        assert rc == 0
+    sub.zero_()
+    t = timeit(subimage_b, 10)
+    print("copy_subimage %-5s %d^2 of %d^2 batched  %6.0f GB/s (%.3f ms per %d images, one call)  %s" % (
+        name, n // 2, n, 2 * sub.numel() / t / 1e9, t * 1e3, batch,
+        parity("copy_subimage batched " + name, sub[batch - 1], T.oracle_copy_subimage(compressor, fmt, blocks[batch - 1].cpu().numpy().tobytes(), n, n, n // 4, n // 4, n // 2, n // 2))))
     colour = (ctypes.c_uint8 * 4)(200, 100, 50, 255)
     def solid():
         for i in range(batch):
@@ -108,6 +126,14 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         print("create_solid %-5s %6.0f GB/s written (%.3f ms per %d images of %d^2, one call per image)  %s" % (
             name, blocks.numel() / t / 1e9, t * 1e3, batch, n,
             parity("create_solid " + name, blocks[0], T.oracle_create_solid(compressor, fmt, n, n, list(colour)))))
+        colours = (ctypes.c_uint8 * (4 * batch))(*[(37 * i + j * 50) & 255 for i in range(batch) for j in range(3)])
+        def solid_b():
+            rc = L.icamd_create_solid_batch_device(compressor, fmt, n, n, batch, colours, ctypes.c_void_p(blocks.data_ptr()), per_in, per_in, sh)
+            assert rc == 0
+        t = timeit(solid_b, 10)
+        print("create_solid %-5s batched %6.0f GB/s written (%.3f ms per %d images of %d^2, one call)  %s" % (
+            name, blocks.numel() / t / 1e9, t * 1e3, batch, n,
+            parity("create_solid batched " + name, blocks[batch - 1], T.oracle_create_solid(compressor, fmt, n, n, [colours[3 * (batch - 1) + j] for j in range(3)] + [0]))))
         blocks.copy_(keep); del keep
     del pout, sub
     if codec == 0:

@@ -532,8 +532,10 @@ def test_slab_sharding_of_one_image_on_device(pkg):
 # ---- "next" rows 8f.2-4: Pad / Downsample / DXT1->ETC1 transcode kernels
 
 def test_blockops_match_oracle(pkg):
+    # every ETC1 strategy: each has its own border kernel (icamd_pad_etc1_border[_split_h|_split_v|_heuristic]_kernel); the three
+    # padded sizes give a rows-and-columns, a columns-only and a rows-only border, i.e. both halves of its index mapping
     for compressor, fmt, strategy in [(T.DXTC, T.RGB, 2), (T.DXTC, T.BGR, 2), (T.DXTC, T.RGBA, 2), (T.ETC, T.RGB, 0),
-                                      (T.ETC, T.RGB, 2), (T.ETC, T.RGB, 3)]:
+                                      (T.ETC, T.RGB, 1), (T.ETC, T.RGB, 2), (T.ETC, T.RGB, 3)]:
         for (h, w) in [(256, 512), (32, 48), (13, 7), (64, 8), (8, 64), (4, 4), (2, 2), (1, 4), (3, 8)]:
             img = T.s_mixed(h, w, T.comps_of(fmt), index=h + w)
             blocks = T.oracle_compress(compressor, fmt, img, h, w, 0, strategy)
@@ -556,6 +558,55 @@ def test_blockops_match_oracle(pkg):
     assert pkg.transcode_dxt1_to_etc1_host(raw) == T.oracle_transcode(raw)
     enc = T.oracle_compress(T.DXTC, T.RGB, T.s_mixed(512, 512, 3, index=4), 512, 512)
     assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)
+
+
+def test_batched_block_operations_match_oracle(pkg):
+    """r05: icamd_pad_batch_device / icamd_copy_subimage_batch_device / icamd_create_solid_batch_device -- n equally shaped
+    grids per launch (padded image strides on the source side), every image against the oracle's per-image result; and the
+    argument checks they share with icamd_downsample_batch_device (a refused geometry is refused for ANY image count)."""
+    import ctypes
+    import torch
+    n = 5
+    for compressor, fmt, strategy in [(T.DXTC, T.RGB, 2), (T.DXTC, T.RGBA, 2), (T.ETC, T.RGB, 0), (T.ETC, T.RGB, 1), (T.ETC, T.RGB, 2),
+                                      (T.ETC, T.RGB, 3)]:
+        for (h, w) in [(64, 96), (12, 8), (4, 4)]:
+            imgs = [T.s_mixed(h, w, T.comps_of(fmt), index=31 * i + h) for i in range(n)]
+            grids = [T.oracle_compress(compressor, fmt, im, h, w, 0, strategy) for im in imgs]
+            per = len(grids[0])
+            src = torch.zeros((n, per + 24), dtype=torch.uint8, device="cuda")  # 24 spare bytes per image: a real stride
+            for i, gbytes in enumerate(grids):
+                src[i, :per] = _dev(np.frombuffer(gbytes, np.uint8))
+            for (ph, pw) in [(h + 9, w + 5), (h, w + 8), (h + 4, w)]:
+                out = pkg.pad_batch_device(compressor, fmt, src, h, w, ph, pw, etc_strategy=strategy)
+                torch.cuda.synchronize()
+                for i in range(n):
+                    assert out[i].cpu().numpy().tobytes() == T.oracle_pad(compressor, fmt, grids[i], h, w, ph, pw, strategy), \
+                        (compressor, fmt, strategy, h, w, ph, pw, i)
+            if h >= 8 and w >= 16:
+                out = pkg.copy_subimage_batch_device(compressor, fmt, src, h, w, 4, 4, h - 4, w - 8)
+                torch.cuda.synchronize()
+                for i in range(n):
+                    assert out[i].cpu().numpy().tobytes() == T.oracle_copy_subimage(compressor, fmt, grids[i], h, w, 4, 4, h - 4, w - 8)
+        colors = [((10 * i + 3) & 255, (255 - 7 * i) & 255, 40 + i, (200 + i) & 255) for i in range(70)]  # more images than one fill launch holds
+        out = pkg.create_solid_batch_device(compressor, fmt, 40, 52, colors)
+        torch.cuda.synchronize()
+        for i, c in enumerate(colors):
+            assert out[i].cpu().numpy().tobytes() == T.oracle_create_solid(compressor, fmt, 40, 52, list(c)[:T.comps_of(fmt)] + [0] * (4 - T.comps_of(fmt))), i
+    # argument checks
+    L = pkg.lib()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    p = ctypes.c_void_p(buf.data_ptr())
+    for count in (0, 1, 3):  # an odd block grid is refused for any count, also for none (ADVICE r04)
+        assert L.icamd_downsample_batch_device(T.DXTC, 2, T.RGB, 12, 16, count, p, 4096, p, 4096, 8, None) == pkg.FALSE
+        assert L.icamd_pad_batch_device(T.DXTC, 2, T.RGB, 16, 16, count, p, 4096, 8, 24, p, 4096, 96, None) == pkg.FALSE  # shrinks
+        assert L.icamd_copy_subimage_batch_device(T.DXTC, T.RGB, 16, 16, count, p, 4096, 2, 0, 8, 8, p, 4096, 32, None) == pkg.FALSE
+    assert L.icamd_downsample_batch_device(T.DXTC, 2, T.RGB, 16, 16, 0, p, 4096, p, 4096, 32, None) == pkg.OK
+    assert L.icamd_downsample_batch_device(T.DXTC, 2, T.RGB, 16, 16, 1, p, 64, p, 4096, 32, None) < 0   # stride < one image
+    assert L.icamd_pad_batch_device(T.DXTC, 2, T.RGB, 16, 16, 2, p, 64, 24, 24, p, 4096, 288, None) < 0
+    assert L.icamd_create_solid_batch_device(T.PVRTC, T.RGBA, 8, 8, 1, (ctypes.c_uint8 * 4)(1, 2, 3, 4), p, 0, 16, None) == pkg.FALSE
+    with pytest.raises(ValueError):
+        pkg.downsample_device(T.DXTC, T.RGB, buf[:64].view(1, -1), 16, 16)  # 64 bytes: a 16 x 16 DXT1 grid has 128
+    torch.cuda.synchronize()
 
 
 def test_mip_chain_in_containers(pkg):

@@ -131,3 +131,19 @@ def test_pvrtc_onepass_kernel_plain_scan_build_still_compiles(tmp_path):
     """-DICAMD_PVRTC_NO_SCAN_SDWA (the early-exit scan as plain C++ instead of the VCC / SDWA sequence) stays buildable."""
     text = _asm("pvrtc_kernels.hip", tmp_path, ["-DICAMD_PVRTC_NO_SCAN_SDWA"])
     assert _kernel_meta(text, "icamd_pvrtc2_onepass_kernel")["scratch"] == 0
+
+
+def test_etc1_encode_kernels_keep_four_waves_per_simd(tmp_path):
+    """The ETC1 encoders are VALU-bound at 0.98 of the issue ceiling WITH four waves per SIMD: the exhaustive
+    search is pinned at 128 VGPRs by amdgpu_waves_per_eu(4) and pays for it with two folded spills (8 bytes of scratch) in
+    the kSmallerError kernels.  Nothing else guards that balance: a compiler update or a source change that spills more --
+    or drops below four waves -- would cost the headline C4 figure silently.  Pinned on the emitted code objects: every
+    encode kernel <= 128 VGPRs; scratch <= 8 bytes for kSmallerError, none for the split and heuristic kernels."""
+    text = _asm("etc1_kernels.hip", tmp_path)
+    for src in ("rgb888", "rgba8"):
+        for variant, max_scratch in (("", 8), ("_split_h", 0), ("_split_v", 0), ("_heuristic", 0)):
+            name = "icamd_etc1_%s%s_kernel" % (src, variant)
+            meta = _kernel_meta(text, name)
+            assert meta["vgprs"] <= 128, (name, meta)  # 512 VGPRs per SIMD lane / 4 waves
+            assert meta["scratch"] <= max_scratch, (name, meta)
+            assert meta["lds"] == 0, (name, meta)
