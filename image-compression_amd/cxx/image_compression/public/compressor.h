@@ -76,4 +76,26 @@ class Compressor {
   virtual bool CopySubimage(const CompressedImage &image, uint32 start_row, uint32 start_column, uint32 height,       \
                             uint32 width, CompressedImage *subimage)
 
+// EXTENSION of this backend (NOT part of the reference's interface, so not virtual and not on the base class: a caller that
+// re-links unchanged never sees it).  The device-resident forms of the hot path, for callers whose pixels already live in
+// HBM -- the path DESIGN.md section 5 measures (1.4 Tpixel/s DXT1) instead of the PCIe-bound host-buffer Compress
+// (15 Gpixel/s).  d_buffer / d_out are device pointers on the current HIP device; the work is enqueued on `hip_stream`
+// (a hipStream_t passed as void *, NULL = the default stream) and NOT synchronised.  out_size is the caller's storage per
+// image and must equal ComputeCompressedDataSize() of the (padded) image, like external CompressedImage storage
+// (compressor4x4_helper.cc:34-41).  Argument meaning and the `false` cases are those of Compress / CompressAndPad
+// (public/compressor.h:77-80, 114-119); a device failure is reported on stderr and returned as false.
+//   CompressDevice         one image                                      -> icamd_compress_device
+//   CompressAndPadDevice   one image over a larger block grid             -> icamd_compress_and_pad_device
+//   CompressBatchDevice    n_images equally shaped images in ONE launch, image i at d_buffer + i * src_image_stride_bytes ->
+//                          d_out + i * dst_image_stride_bytes              -> icamd_encode_device
+#define ICAMD_DECLARE_DEVICE_EXTENSION()                                                                              \
+  bool CompressDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padding_bytes_per_row,     \
+                      const void *d_buffer, void *d_out, size_t out_size, void *hip_stream);                         \
+  bool CompressAndPadDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padded_height,       \
+                            uint32 padded_width, uint32 padding_bytes_per_row, const void *d_buffer, void *d_out,    \
+                            size_t out_size, void *hip_stream);                                                      \
+  bool CompressBatchDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padding_bytes_per_row,\
+                           uint32 n_images, const void *d_buffer, size_t src_image_stride_bytes, void *d_out,        \
+                           size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream)
+
 #endif  // IMAGE_COMPRESSION_PUBLIC_COMPRESSOR_H_

@@ -14,6 +14,7 @@ class DxtcCompressor : public Compressor {
   virtual ~DxtcCompressor();
 
   ICAMD_DECLARE_COMPRESSOR_OVERRIDES();
+  ICAMD_DECLARE_DEVICE_EXTENSION();  // extension: device-resident hot path (compressor.h)
 };
 
 }  // namespace image_codec_compression

@@ -24,6 +24,7 @@ class EtcCompressor : public Compressor {
   CompressionStrategy GetCompressionStrategy() const { return compression_strategy_; }
 
   ICAMD_DECLARE_COMPRESSOR_OVERRIDES();
+  ICAMD_DECLARE_DEVICE_EXTENSION();  // extension: device-resident hot path (compressor.h)
 
  private:
   CompressionStrategy compression_strategy_;

@@ -15,6 +15,7 @@ class PvrtcCompressor : public Compressor {
   virtual ~PvrtcCompressor();
 
   ICAMD_DECLARE_COMPRESSOR_OVERRIDES();
+  ICAMD_DECLARE_DEVICE_EXTENSION();  // extension: device-resident hot path (compressor.h)
 };
 
 }  // namespace image_codec_compression

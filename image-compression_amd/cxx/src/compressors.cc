@@ -331,6 +331,65 @@ bool PvrtcCompressor::CopySubimage(const CompressedImage &, uint32, uint32, uint
   return false;
 }
 
+// ------------------------------------------- extension: device-resident hot path (compressor.h, not in the reference)
+
+namespace {
+// Compress / CompressAndPad of one image whose pixels and output live in HBM.
+bool DeviceOne(int compressor, int etc_strategy, CompressedImage::Format format, uint32 height, uint32 width,
+               uint32 padded_height, uint32 padded_width, uint32 padding_bytes_per_row, const void *d_buffer, void *d_out,
+               size_t out_size, void *hip_stream, bool and_pad) {
+  if (!d_buffer || !d_out || height == 0 || width == 0) return false;
+  return and_pad ? ReportStatus(icamd_compress_and_pad_device(compressor, etc_strategy, format, height, width, padded_height,
+                                                              padded_width, padding_bytes_per_row, d_buffer, d_out, out_size,
+                                                              hip_stream),
+                                "icamd_compress_and_pad_device")
+                 : ReportStatus(icamd_compress_device(compressor, etc_strategy, format, height, width, padding_bytes_per_row,
+                                                      d_buffer, d_out, out_size, hip_stream),
+                                "icamd_compress_device");
+}
+// n equally shaped images, one launch.  codec / components as DxtcCompressor / EtcCompressor / PvrtcCompressor::Compress map
+// the format (dxtc_compressor.cc:741-749, etc_compressor.cc:751-754, pvrtc_compressor.cc:664).
+bool DeviceBatch(int compressor, int etc_strategy, CompressedImage::Format format, uint32 height, uint32 width,
+                 uint32 padding_bytes_per_row, uint32 n_images, const void *d_buffer, size_t src_image_stride_bytes, void *d_out,
+                 size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
+  if (!d_buffer || !d_out || height == 0 || width == 0) return false;
+  if (!icamd_supports_format(compressor, format) && compressor != ICAMD_COMPRESSOR_PVRTC) return false;
+  if (out_size_per_image != icamd_compute_compressed_data_size(compressor, format, height, width)) return false;
+  if (n_images > 1 && dst_image_stride_bytes < out_size_per_image) return false;
+  const int comps = compressor == ICAMD_COMPRESSOR_PVRTC ? 4 : (int)GetNumFormatComponents(format);
+  const int codec = compressor == ICAMD_COMPRESSOR_PVRTC ? ICAMD_PVRTC2
+                    : compressor == ICAMD_COMPRESSOR_ETC ? ICAMD_ETC1 : (comps == 3 ? ICAMD_DXT1 : ICAMD_DXT5);
+  const int swap = (format == CompressedImage::kBGR || format == CompressedImage::kBGRA) ? 1 : 0;
+  const uint32 stride = width * (uint32)comps + padding_bytes_per_row;
+  return ReportStatus(icamd_encode_device(codec, etc_strategy, comps, swap, height, width, height, width, stride, n_images,
+                                          src_image_stride_bytes, dst_image_stride_bytes, d_buffer, d_out, hip_stream),
+                      "icamd_encode_device");
+}
+}  // namespace
+
+#define ICAMD_DEFINE_DEVICE_EXTENSION(CLASS, COMPRESSOR, STRATEGY)                                                             \
+  bool CLASS::CompressDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padding_bytes_per_row,        \
+                             const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) {                           \
+    return DeviceOne(COMPRESSOR, STRATEGY, format, height, width, height, width, padding_bytes_per_row, d_buffer, d_out,       \
+                     out_size, hip_stream, false);                                                                             \
+  }                                                                                                                            \
+  bool CLASS::CompressAndPadDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padded_height,          \
+                                   uint32 padded_width, uint32 padding_bytes_per_row, const void *d_buffer, void *d_out,       \
+                                   size_t out_size, void *hip_stream) {                                                        \
+    return DeviceOne(COMPRESSOR, STRATEGY, format, height, width, padded_height, padded_width, padding_bytes_per_row, d_buffer,\
+                     d_out, out_size, hip_stream, true);                                                                       \
+  }                                                                                                                            \
+  bool CLASS::CompressBatchDevice(CompressedImage::Format format, uint32 height, uint32 width, uint32 padding_bytes_per_row,   \
+                                  uint32 n_images, const void *d_buffer, size_t src_image_stride_bytes, void *d_out,           \
+                                  size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {                \
+    return DeviceBatch(COMPRESSOR, STRATEGY, format, height, width, padding_bytes_per_row, n_images, d_buffer,                 \
+                       src_image_stride_bytes, d_out, dst_image_stride_bytes, out_size_per_image, hip_stream);                 \
+  }
+ICAMD_DEFINE_DEVICE_EXTENSION(DxtcCompressor, ICAMD_COMPRESSOR_DXTC, 0)
+ICAMD_DEFINE_DEVICE_EXTENSION(EtcCompressor, ICAMD_COMPRESSOR_ETC, compression_strategy_)
+ICAMD_DEFINE_DEVICE_EXTENSION(PvrtcCompressor, ICAMD_COMPRESSOR_PVRTC, 0)
+#undef ICAMD_DEFINE_DEVICE_EXTENSION
+
 // ------------------------------------------------------------ transcoder
 
 void TranscodeDxt1ToEtc1(CompressedImage *image) {  // dxtc_to_etc_transcoder.cc:29-40: in place, data only

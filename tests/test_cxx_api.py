@@ -60,3 +60,17 @@ def test_cxx_pvrtc_decompress_opt_in_extension():
     assert len(base) == len(ext)
     changed = [(a, b) for a, b in zip(base, ext) if a != b]
     assert changed and all(a == "  decompress -> false" and b.startswith("  decompress -> true hash=") for a, b in changed)
+
+
+@pytest.mark.gpu
+def test_cxx_device_resident_extension_equals_the_host_drop_in():
+    """r05: CompressDevice / CompressAndPadDevice / CompressBatchDevice on DxtcCompressor / EtcCompressor / PvrtcCompressor
+    (an extension, compressor.h) leave in HBM exactly the bytes the host-buffer drop-in returns -- whose transcript is pinned
+    against the reference above -- for every format / strategy / ragged shape / padded grid, and refuse what it refuses."""
+    exe = os.path.join(BUILD, "device_driver_amd")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(T.ROOT, "tests", "cxx"), exe], stdout=subprocess.DEVNULL)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "all equal" in out.splitlines()[-1], out[-3000:]
+    assert "DIFFERENT" not in out and int(out.splitlines()[-1].split()[2]) >= 90
