@@ -126,10 +126,18 @@ struct TlsWorkspace {
   Workspace &get() {
     Workspace *&w = p[slot];
     if (!w) {
+      // (created on first use only: a thread whose launches all take the one-pass kernel never owns a workspace, and
+      // slot 1 exists only in threads that really alternate between two streams)
+      int dev = -1;
+      (void)hipGetDevice(&dev);
       std::lock_guard<std::mutex> lock(g_ws_mutex);
       if (!g_ws_parked.empty()) {
-        w = g_ws_parked.back();
-        g_ws_parked.pop_back();
+        // prefer a parked workspace of THIS device: taking another device's costs a hipFree + hipMalloc in acquire()
+        size_t pick = g_ws_parked.size() - 1;
+        for (size_t i = 0; i < g_ws_parked.size(); ++i)
+          if (g_ws_parked[i]->device == dev) { pick = i; break; }
+        w = g_ws_parked[pick];
+        g_ws_parked.erase(g_ws_parked.begin() + (long)pick);
       } else {
         w = new Workspace();
       }
@@ -371,17 +379,23 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
     // DMA: this wave's ring (all 64 lanes of a wave share the strip row and the image when the region is >= 64 columns wide)
     // (r04) the wave's index is made a scalar explicitly: the ring slot (M0) is then computed on the scalar unit instead of
     // two v_readfirstlane + vector adds per pixel row (encode kernel 268.0 -> 264.4 us, profiles/r04_ab_pvrtc_scalar_ring.log).
-    // The same for the strip's row (readfirstlane of by0 * 4 feeding the DMA addresses as an SGPR pair) was tried and is NOT
-    // used: it produced wrong first blocks of strips, deterministically per build, although lane 0's value broadcast through
-    // a VGPR gives exact results -- an issue of the SGPR-operand code path that was not tracked down (same log).
+    // The same for the strip's row (readfirstlane of by0 * 4, -DICAMD_PVRTC_SCALAR_ROW) produced wrong first blocks of strips
+    // in r04.  r05 found why: not the SGPR operands, but the colour loads' wait (load_colours below) -- that build merely
+    // scheduled differently.  With the wait fixed the scalar-row build is bit-exact; it stays an A/B option (the kernel now
+    // only serves launches the one-pass kernel does not take).
     const uint32_t wave_s = DMA ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x >> 6;
     lds_u32 *ring = DMA ? (lds_u32 *)(lds_rows + wave_s * (kRowRing * 512u)) : nullptr;
     const uint32_t ring_lane_byte = DMA ? (uint32_t)(uintptr_t)ring + (threadIdx.x & 63u) * 16u : 0u;
     // pixel row r of the strip -> slot r % kRowRing.  The walk ends at row 4 K (the first row below the strip); the three
     // requests past it keep the wait counts uniform but re-fetch row 4 K (an L2 hit) instead of 3 / 32 more HBM bytes.
     const uint32_t last_row = 4u << sb;
+#if defined(ICAMD_PVRTC_SCALAR_ROW)  // r04's failing experiment, kept reproducible (profiles/r04_ab_pvrtc_scalar_ring.log)
+    const uint32_t by0_dma = (uint32_t)__builtin_amdgcn_readfirstlane((int)by0);
+#else
+    const uint32_t by0_dma = by0;
+#endif
     auto dma_row = [&](uint32_t r) {
-      const uint32_t *q = img + ((((by0 * 4u + (r < last_row ? r : last_row)) & (n - 1u)) << log2_n) + bx * 8u);
+      const uint32_t *q = img + ((((by0_dma * 4u + (r < last_row ? r : last_row)) & (n - 1u)) << log2_n) + bx * 8u);
       lds_u32 *slot = ring + (r & (kRowRing - 1u)) * 512u;
       __builtin_amdgcn_global_load_lds(q, slot, 16, 0, 0);             // lane l: its first four pixels -> slot + 16 l
       __builtin_amdgcn_global_load_lds(q + 4, slot + 256, 16, 0, 0);   // ... its last four -> slot + 1024 + 16 l
@@ -466,7 +480,12 @@ __device__ __forceinline__ void pvrtc2_encode(const PvrtcLaunch &L, uint32_t wg,
         uint2 l, m, r;
         asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %4, off\n\tglobal_load_dwordx2 %2, %5, off"
                      : "=&v"(l), "=&v"(m), "=&v"(r) : "v"(row + xl), "v"(row + bx), "v"(row + xr) : "memory");
-        if (j <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The wait must CARRY the loaded registers ("+v"): an asm volatile without operands only orders against other volatile
+        // asm and memory operations, and the scheduler is free to place a pure-VALU use of l / m / r between the load asm and a
+        // wait that does not name them.  That is what broke r04's scalar-row build (uses of the first colour row scheduled in
+        // front of the wait: wrong first blocks of strips, deterministic per build -- profiles/r04_ab_pvrtc_scalar_ring.log;
+        // root-caused in r05) and what the shipped build escaped only by scheduling luck.
+        if (j <= 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(l), "+v"(m), "+v"(r) :: "memory");
         requested = c;
         c[0].a = l.x; c[0].b = l.y;
         c[1].a = m.x; c[1].b = m.y;

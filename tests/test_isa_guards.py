@@ -147,3 +147,41 @@ def test_etc1_encode_kernels_keep_four_waves_per_simd(tmp_path):
             assert meta["vgprs"] <= 128, (name, meta)  # 512 VGPRs per SIMD lane / 4 waves
             assert meta["scratch"] <= max_scratch, (name, meta)
             assert meta["lds"] == 0, (name, meta)
+
+
+@pytest.mark.parametrize("flags", [[], ["-DICAMD_PVRTC_SCALAR_ROW"]])
+def test_pvrtc_encode_kernel_colour_rows_are_not_used_before_their_wait(tmp_path, flags):
+    """ADVICE r04 / r05 root cause: colour rows -1, 0 and 1 of a strip are loaded by one inline asm and waited for by a
+    SECOND asm (`s_waitcnt vmcnt(0)`).  Until r05 that wait named no operands, so nothing stopped hipcc from scheduling a
+    VALU use of a just-requested register in front of it -- which is exactly what r04's scalar-row build did (wrong first
+    blocks of strips).  The wait now carries the registers as "+v" operands; this pins the consequence on the emitted code of
+    the shipped build AND of the build that used to break: between such a load group and the vmcnt(0) that follows it, no
+    instruction names one of its destination registers."""
+    text = _asm("pvrtc_kernels.hip", tmp_path, flags)
+    body = _body(text, "icamd_pvrtc2_encode_kernel")
+    groups = 0
+    i = 0
+    while i < len(body):
+        if not re.match(r"\s+global_load_dwordx2\s", body[i]):
+            i += 1
+            continue
+        dests, j = set(), i
+        while j < len(body) and (re.match(r"\s+global_load_dwordx2\s", body[j]) or body[j].strip().startswith(";")):
+            if "global_load_dwordx2" in body[j]:
+                dests |= _regs(body[j].split("global_load_dwordx2")[1].split(",")[0])
+            j += 1
+        wait = next((k for k in range(j, min(j + 60, len(body))) if re.match(r"\s+s_waitcnt vmcnt\(0\)", body[k])), None)
+        nxt_branch = next((k for k in range(j, min(j + 60, len(body))) if re.match(r"\s+s_cbranch", body[k])), None)
+        if len(dests) == 6 and wait is not None and (nxt_branch is None or True):
+            # (the in-loop group for j >= 2 branches around its vmcnt(0); only the straight-line distance to the wait is
+            # checked here, the branched case is test_pvrtc_encode_kernel_hand_counted_waits_still_hold's)
+            for l in body[j:wait]:
+                m = re.match(r"\s+([a-z_0-9]+)\s+(.*?)(;.*)?$", l)
+                if not m or m.group(1).startswith("s_") or l.strip().startswith((";", ".")):
+                    continue
+                if nxt_branch is not None and nxt_branch < wait:
+                    break
+                assert not (_regs(m.group(2)) & dests), "v%s used before the wait for its load: %s" % (sorted(_regs(m.group(2)) & dests), l.strip())
+            groups += 1
+        i = j
+    assert groups >= 2, groups  # colour rows -1 and 0 in front of the strip loop
