@@ -57,6 +57,8 @@ WORKLOADS = {
     "etc1_rgb888": (2, 3, 3.5, "ETC1", "valu"),
     "etc1_rgba8": (2, 4, 4.5, "ETC1", "valu"),
     "pvrtc2_rgba8": (3, 4, 4.25, "PVRTC1-2bpp", "valu"),
+    # EXTENSION, parity unpinned (the reference has no 4 bpp mode): checked against the oracle's restatement and by decoding
+    "pvrtc4_rgba8": (4, 4, 4.5, "PVRTC1-4bpp", "valu"),
 }
 
 # BASELINE.json configs[1..4] (configs[0] is the reference's own CPU case = the cpu_baseline leg).
@@ -72,6 +74,10 @@ CONFIGS = {
                     "GPUs (texture_range per rank, RCCL gather)"),
     "c5": dict(workload="pvrtc2_rgba8", size=4096, batch=16,
                text="PVRTC 2bpp encode 4096x4096 on 1x MI355X (the reference has no 4bpp mode, SURVEY D3)"),
+    # not a BASELINE-pinned leg: config 5's literal "PVRTC 4bpp" as an EXTENSION (no reference implementation to pin it to)
+    "c5_4bpp": dict(workload="pvrtc4_rgba8", size=4096, batch=16,
+                    text="PVRTC 4bpp encode 4096x4096 on 1x MI355X -- EXTENSION, parity unpinned: the 2bpp rules of the "
+                         "reference with 4x4 blocks (SURVEY D3); checked against the oracle's restatement and by decoding"),
 }
 
 
@@ -80,7 +86,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json configuration preset")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json configuration preset")  # (+ c5_4bpp)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--size", type=int, default=None, help="texture width = height")
     ap.add_argument("--batch", type=int, default=None, help="textures per rank per step (one launch)")
@@ -169,16 +175,16 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
     threads = max(1, cores)
     # bounded: ETC1 exhaustive search is ~10x slower per pixel, so sample a band of rows for it
     rows = size if codec != 2 else max(4, min(size, (1 << 22) // size // 4 * 4))
-    sample = host_img[:rows] if codec != 3 else host_img
-    if codec == 3:
+    sample = host_img[:rows] if codec not in (3, 4) else host_img
+    if codec in (3, 4):
         rows = size
     # one untimed pass (thread start-up, page faults), then about a second of wall time of back-to-back passes: on a
     # 256-thread host that is ~90 passes of a 4096^2 DXT1 texture = ~15 s of single-core work
-    out = T.oracle_encode(codec, sample, rows, size, comps, 0, strategy, threads=threads if codec != 3 else 1)
+    out = T.oracle_encode(codec, sample, rows, size, comps, 0, strategy, threads=threads if codec not in (3, 4) else 1)
     t0 = time.perf_counter()
     reps = 0
     while True:
-        out = T.oracle_encode(codec, sample, rows, size, comps, 0, strategy, threads=threads if codec != 3 else 1)
+        out = T.oracle_encode(codec, sample, rows, size, comps, 0, strategy, threads=threads if codec not in (3, 4) else 1)
         reps += 1
         if time.perf_counter() - t0 > 1.0 or reps >= 200:
             break
@@ -194,6 +200,10 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
         # the compiled reference itself (oracle/_ref, built from /root/reference in the build container and shipped
         # as a binary): single thread, its own entry point -- DXT1/ETC1 only exist for 3-byte pixels there
         import numpy as np
+        if codec == 4:  # extension: the reference has no PVRTC 4 bpp
+            return {"reference_single_thread": None, "value": rows * size / dt / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                    "single_thread_value": rows * size / dt1 / 1e6,
+                    "sample": "oracle/ic_oracle.c pvrtc4_encode_image (extension, parity unpinned), one %dx%d texture, %d passes" % (size, size, reps)}
         compressor = {0: T.DXTC, 1: T.DXTC, 2: T.ETC, 3: T.PVRTC}[codec]
         fmt = {0: T.RGB, 1: T.RGBA, 2: T.RGB, 3: T.RGBA}[codec]
         rimg = sample if T.comps_of(fmt) == comps else np.ascontiguousarray(sample[..., :3])
@@ -207,12 +217,12 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
                                                                        {T.RGB: "kRGB", T.RGBA: "kRGBA"}[fmt])}
     return {
         "reference_single_thread": ref_info,
-        "value": rows * size / dt / 1e6, "unit": "Mpixels/s", "cores": threads if codec != 3 else 1, "kind": "port",
+        "value": rows * size / dt / 1e6, "unit": "Mpixels/s", "cores": threads if codec not in (3, 4) else 1, "kind": "port",
         "single_thread_value": rows * size / dt1 / 1e6,
         "sample": "oracle/ic_oracle.c (plain-C port of the reference, -O2), %dx%d px of one workload texture, "
                   "%d timed pass(es) after one untimed, slab-parallel over block rows with %d pthreads (= %.1f s of "
                   "single-core work); plus %d single-thread passes of the port and of the compiled reference"
-                  % (size, rows, reps, threads if codec != 3 else 1, reps * dt1, single_passes),
+                  % (size, rows, reps, threads if codec not in (3, 4) else 1, reps * dt1, single_passes),
     }
 
 
@@ -482,7 +492,8 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     graph = None
     try:
         gs = torch.cuda.Stream(device=src.device)
-        ws = torch.empty(max(1, pkg.pvrtc_workspace_size(size, 1)), dtype=torch.uint8, device=src.device) if codec == 3 else None
+        ws = torch.empty(max(1, pkg.pvrtc_workspace_size(size, 1) if codec == 3 else pkg.pvrtc4_workspace_size(size, 1)),
+                         dtype=torch.uint8, device=src.device) if codec in (3, 4) else None
         with torch.cuda.stream(gs):
             if ws is not None:
                 pkg.pvrtc_set_workspace(ws)
@@ -819,9 +830,16 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
             step(outs[0])
             ctx.sync()
-            want = T.oracle_encode(codec, src[0].cpu().numpy(), size, size, comps, 0, strategy, threads=1 if codec == 3 else cores)
+            host0 = src[0].cpu().numpy()
+            want = T.oracle_encode(codec, host0, size, size, comps, 0, strategy, threads=1 if codec in (3, 4) else cores)
             res["parity"] = "bit-exact vs oracle (texture 0 of the batch)" if outs[0][0].cpu().numpy().tobytes() == want \
                 else "MISMATCH vs oracle"
+            if codec == 4:  # no reference exists: the oracle is a second form of the same rules, the decode the only outside check
+                import numpy as np
+                dec = T.oracle_decode(4, want, size, size).reshape(size, size, 4).astype(np.float64)
+                mse = float(((dec - host0.astype(np.float64)) ** 2).mean())
+                res["parity"] += " -- EXTENSION, parity UNPINNED (no reference implementation of PVRTC 4 bpp)"
+                res["round_trip_psnr_db"] = None if mse == 0 else round(10.0 * math.log10(255.0 * 255.0 / mse), 2)
     del src, outs
     if ctx.on_gpu:
         torch.cuda.empty_cache()
@@ -871,7 +889,7 @@ def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_
     if ctx.rank == 0:
         last = gathered[(steps - 1) & 1]
         ok = bool(torch.equal(last[0], outs[(steps - 1) & 1]))
-    out_bytes_all = pixels_per_step_all / 16.0 * (16 if codec == 1 else 8) if codec != 3 else pixels_per_step_all / 4.0
+    out_bytes_all = pixels_per_step_all / 4.0 if codec == 3 else pixels_per_step_all / 16.0 * (16 if codec == 1 else 8)  # (4 bpp = DXT1's rate)
     world = ctx.world
     bound = gather_bound(probe, out_bytes_all, world, pixels_per_step_all)
     return {**bound, "value_with_gather": round(pixels_per_step_all * steps / elapsed_g / 1e6, 1),
@@ -1178,7 +1196,7 @@ def main():
             got = outs[0][0].cpu().numpy().tobytes()
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
             want = T.oracle_encode(codec, host0, size, size, comps, 0, args.etc_strategy,
-                                   threads=1 if codec == 3 else cores)
+                                   threads=1 if codec in (3, 4) else cores)
             result["parity"] = "bit-exact vs oracle (texture 0 of the batch)" if got == want else "MISMATCH vs oracle"
             if got != want:
                 print(json.dumps(result))
@@ -1238,7 +1256,7 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_extra_configs:
             configs = {}
-            for name in ("c3", "c4", "c5"):
+            for name in ("c3", "c4", "c5", "c5_4bpp"):
                 try:
                     configs[name] = preset_leg(ctx, pkg, sharding, name, args.extra_steps, verify=not args.no_verify,
                                                gather=not args.no_gather, probe=probe)

@@ -30,13 +30,14 @@ COMPRESSOR_DXTC, COMPRESSOR_ETC, COMPRESSOR_PVRTC = 0, 1, 2
 RGB, BGR, RGBA, BGRA = 0, 1, 2, 3
 ETC_SPLIT_HORIZONTALLY, ETC_SPLIT_VERTICALLY, ETC_SMALLER_ERROR, ETC_HEURISTIC = 0, 1, 2, 3
 DXT1, DXT5, ETC1, PVRTC2 = 0, 1, 2, 3
+PVRTC4 = 4  # EXTENSION, parity unpinned: PVRTC1 4 bpp (include/ic_amd.h); icamd_encode_device only
 OK, FALSE = 0, 1
 
 EXPORTS = [
     "icamd_compute_compressed_data_size", "icamd_supports_format", "icamd_encoded_size", "icamd_compress",
     "icamd_compress_and_pad", "icamd_compress_device", "icamd_compress_and_pad_device", "icamd_encode_device",
     "icamd_decode_device", "icamd_decompress", "icamd_pad_device", "icamd_pad", "icamd_downsample_device",
-    "icamd_downsample", "icamd_downsample_batch_device", "icamd_pad_batch_device", "icamd_create_solid_batch_device", "icamd_copy_subimage_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size",
+    "icamd_downsample", "icamd_downsample_batch_device", "icamd_pad_batch_device", "icamd_create_solid_batch_device", "icamd_copy_subimage_batch_device", "icamd_transcode_dxt1_to_etc1_device", "icamd_transcode_dxt1_to_etc1", "icamd_compress_batch", "icamd_pvrtc2_encode_region_device", "icamd_pvrtc2_workspace_size", "icamd_pvrtc4_workspace_size",
     "icamd_pvrtc2_set_workspace", "icamd_pvrtc2_tune", "icamd_host_register", "icamd_host_unregister", "icamd_pvrtc2_decompress", "icamd_device_count", "icamd_last_error", "icamd_version", "icamd_kernel_name",
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
@@ -106,6 +107,9 @@ def lib():
         if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_workspace_size"):  # older A/B builds lack it
             L.icamd_pvrtc2_workspace_size.restype = _sz
             L.icamd_pvrtc2_workspace_size.argtypes = [_u32, _u32]
+            if hasattr(L, "icamd_pvrtc4_workspace_size"):
+                L.icamd_pvrtc4_workspace_size.restype = _sz
+                L.icamd_pvrtc4_workspace_size.argtypes = [_u32, _u32]
             L.icamd_pvrtc2_set_workspace.restype = _ci
             L.icamd_pvrtc2_set_workspace.argtypes = [_vp, _sz]
         if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_tune"):
@@ -350,6 +354,10 @@ def pvrtc_decompress_host(blocks, size):
 
 def pvrtc_workspace_size(size, n_images=1):
     return lib().icamd_pvrtc2_workspace_size(size, n_images)
+
+
+def pvrtc4_workspace_size(size, n_images=1):
+    return lib().icamd_pvrtc4_workspace_size(size, n_images)
 
 
 def pvrtc_tune(mode=0, log2_strip=-1):

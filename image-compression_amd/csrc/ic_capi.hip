@@ -250,6 +250,7 @@ const char *icamd_kernel_name(int codec, int src_components) {
     case ICAMD_DXT1: case ICAMD_DXT5: return icamd::dxt_kernel_name(codec, src_components);
     case ICAMD_ETC1: return icamd::etc1_kernel_name(src_components);
     case ICAMD_PVRTC2: return icamd::pvrtc2_kernel_name();
+    case ICAMD_PVRTC4: return icamd::pvrtc4_kernel_name();
   }
   return "";
 }
@@ -273,6 +274,7 @@ size_t icamd_compute_compressed_data_size(int compressor, int format, uint32_t h
 
 size_t icamd_encoded_size(int codec, uint32_t grid_height, uint32_t grid_width) {
   if (codec == ICAMD_PVRTC2) return (size_t)grid_width * grid_height / 4;
+  if (codec == ICAMD_PVRTC4) return (size_t)grid_width * grid_height / 2;
   return (size_t)num_blocks4(grid_height) * num_blocks4(grid_width) * (codec == ICAMD_DXT5 ? 16u : 8u);
 }
 
@@ -291,6 +293,25 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
   if (codec == ICAMD_PVRTC2)
     return pvrtc_encode_device_impl(src_components, height, width, row_stride_bytes, n_images, src_image_stride_bytes,
                                     dst_image_stride_bytes, d_src, d_dst, stream, false);
+  if (codec == ICAMD_PVRTC4) {
+    // EXTENSION (parity unpinned, include/ic_amd.h): PVRTC1 4 bpp under the preconditions of PvrtcCompressor::Compress
+    // (pvrtc.cc:636-650: square power of two, RGBA8888, no row padding), at least 8 x 8
+    if (!is_pow2(width) || width != height || width < 8u || width >= 65536u) return ICAMD_FALSE;
+    if (src_components != 4 || row_stride_bytes != width * 4u) return ICAMD_FALSE;
+    if (reinterpret_cast<uintptr_t>(d_src) % 16u || reinterpret_cast<uintptr_t>(d_dst) % 8u ||
+        (n_images > 1 && (src_image_stride_bytes % 16u || dst_image_stride_bytes % 8u)))
+      return fail(ICAMD_ERR_ARG, "PVRTC: source must be 16-byte aligned, output 8-byte aligned");
+    icamd::PvrtcParams P;
+    P.src = static_cast<const uint8_t *>(d_src);
+    P.dst = static_cast<uint8_t *>(d_dst);
+    P.src_image_stride = src_image_stride_bytes;
+    P.dst_image_stride = dst_image_stride_bytes;
+    P.size = width;
+    P.log2_size = ilog2(width);
+    P.n_images = n_images;
+    ICAMD_HIP(icamd::launch_pvrtc4(P, stream), "launch pvrtc4");
+    return ICAMD_OK;
+  }
   if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1) return fail(ICAMD_ERR_ARG, "unknown codec");
   if (codec == ICAMD_DXT5 && src_components != 4) return fail(ICAMD_ERR_ARG, "DXT5 needs a 4-component source");
   if (row_stride_bytes < width * (uint32_t)src_components) return fail(ICAMD_ERR_ARG, "row stride smaller than a row");
@@ -358,6 +379,11 @@ int icamd_host_unregister(void *host_ptr) {
 size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images) {
   if (!is_pow2(size) || size < 8) return 0;
   return icamd::pvrtc2_workspace_bytes(size, n_images);
+}
+
+size_t icamd_pvrtc4_workspace_size(uint32_t size, uint32_t n_images) {
+  if (!is_pow2(size) || size < 8) return 0;
+  return icamd::pvrtc4_workspace_bytes(size, n_images);
 }
 
 int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {

@@ -72,6 +72,10 @@ struct PvrtcParams {
   bool internal_workspace = false;
 };
 hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream);
+// PVRTC1 4 bpp (extension, parity unpinned): same parameters (no regions), 4 x 4-pixel blocks, size * size / 2 bytes per image
+hipError_t launch_pvrtc4(const PvrtcParams &P, hipStream_t stream);
+size_t pvrtc4_workspace_bytes(uint32_t size, uint32_t n_images);
+const char *pvrtc4_kernel_name();
 // Scratch the PVRTC encoder needs between its two kernels for n_images size x size textures (8 bytes per block of one
 // launch group), and the thread-local caller-owned override of the library's internal scratch buffer.
 size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images);

@@ -324,6 +324,30 @@ ICAMD_DEV void pvrtc_row_mods_v(const uint32_t V[3][4], const uint32_t *pixels, 
   }
 }
 
+// The same from the walk's own bases (one-pass kernel, r05): P0 / D0 = first value and step of the left half row (x_in 0..3,
+// sources left | centre), P1 / D1 of the right half row (centre | right).  Both are linear in the vertical weight, so the
+// strip walk steps THEM from pixel row to pixel row (16 adds) instead of stepping the three column blends and re-deriving
+// P and D in every row (12 + 16).  The bases are left untouched: pixel j uses base + j * step built by three-operand adds.
+ICAMD_DEV void pvrtc_row_mods_pd(const uint32_t P0[4], const uint32_t D0[4], const uint32_t P1[4], const uint32_t D1[4],
+                                 const uint32_t *pixels, uint32_t row[2]) {
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t *Pb = h ? P1 : P0, *D = h ? D1 : D0;
+    uint32_t P[4] = { Pb[0], Pb[1], Pb[2], Pb[3] };
+    uint32_t acc = 0;
+    ICAMD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      acc = opaque(accumulate_mod(pixels[4 * h + j], P, 1u << (8 * j), acc));
+      ICAMD_SCHED_FENCE();
+      if (j < 3) {
+        ICAMD_UNROLL
+        for (int v = 0; v < 4; ++v) P[v] += D[v];
+      }
+    }
+    row[h] = acc;
+  }
+}
+
 template <bool WITH_RIGHT>
 ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB bot[3], const uint32_t *pixels,
                               uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
@@ -821,37 +845,55 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
         A[c][v] = b[v];
       }
     }
+#if !defined(ICAMD_PVRTC_ONEPASS_STEP_V)
+    // ... and from them the bases of the horizontal walks and THEIR steps per pixel row (pvrtc_row_mods_pd; everything is
+    // linear in the vertical weight, and sums / shifts commute modulo 2^32, so stepping these equals re-deriving them):
+    //   left half row:  D = V[1] - V[0],  P = 4 (V[0] + V[1]);     right half row:  D = V[2] - V[1],  P = 8 V[1]
+    uint32_t P0[4], D0[4], P1[4], D1[4], dP0[4], dD0[4], dP1[4], dD1[4];
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) {
+      D0[v] = V[1][v] - V[0][v];      dD0[v] = dV[1][v] - dV[0][v];
+      P0[v] = (V[0][v] + V[1][v]) << 2; dP0[v] = (dV[0][v] + dV[1][v]) << 2;
+      D1[v] = V[2][v] - V[1][v];      dD1[v] = dV[2][v] - dV[1][v];
+      P1[v] = V[1][v] << 3;           dP1[v] = dV[1][v] << 3;
+    }
+#define ICAMD_ROW_MODS(px_, row_) pvrtc_row_mods_pd(P0, D0, P1, D1, px_, row_)
+#define ICAMD_ROW_STEP()                                                                             \
+  ICAMD_UNROLL                                                                                       \
+  for (int v = 0; v < 4; ++v) { P0[v] += dP0[v]; D0[v] += dD0[v]; P1[v] += dP1[v]; D1[v] += dD1[v]; }
+#else
+#define ICAMD_ROW_MODS(px_, row_) pvrtc_row_mods_v<false>(V, px_, 0u, row_, nullptr)
+#define ICAMD_ROW_STEP()                                      \
+  ICAMD_UNROLL                                                \
+  for (int c = 0; c < 3; ++c)                                 \
+    ICAMD_UNROLL                                              \
+    for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+#endif
     uint32_t row[2];
     if (s >= 1) {  // row 2 of block s-1, weight 0
-      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      ICAMD_ROW_MODS(ep, row);
       acc.hc = sad_u8(prev[0], row[0], acc.hc);  // "horizontal_count" = sum |m - m(x, y+1)| (pvrtc.cc:426-429)
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
       pvrtc_acc_row<true>(acc, 2, row, 0u);
       prev[0] = row[0]; prev[1] = row[1];
     }
-    ICAMD_UNROLL
-    for (int c = 0; c < 3; ++c)
-      ICAMD_UNROLL
-      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_ROW_STEP()
     ICAMD_SCHED_FENCE();
     tick(4 * s + 4, mp, ep);
     pvrtc_keys_row<0>(keys, mp);
     if (s >= 1) {  // row 3 of block s-1, weight 1
-      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      ICAMD_ROW_MODS(ep, row);
       acc.hc = sad_u8(prev[0], row[0], acc.hc);
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
       pvrtc_acc_row<true>(acc, 3, row, 0u);
       prev[0] = row[0]; prev[1] = row[1];
     }
-    ICAMD_UNROLL
-    for (int c = 0; c < 3; ++c)
-      ICAMD_UNROLL
-      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_ROW_STEP()
     ICAMD_SCHED_FENCE();
     tick(4 * s + 5, mp, ep);
     pvrtc_keys_row<1>(keys, mp);
     if (s >= 0) {  // row 0 of block s, weight 2 -- for s == K the row below the strip, which only completes block K-1
-      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      ICAMD_ROW_MODS(ep, row);
       if (s >= 1) {
         acc.hc = sad_u8(prev[0], row[0], acc.hc);
         acc.hc = sad_u8(prev[1], row[1], acc.hc);
@@ -863,15 +905,12 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
       pvrtc_acc_row<true>(acc, 0, row, 0u);
       prev[0] = row[0]; prev[1] = row[1];
     }
-    ICAMD_UNROLL
-    for (int c = 0; c < 3; ++c)
-      ICAMD_UNROLL
-      for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+    ICAMD_ROW_STEP()
     ICAMD_SCHED_FENCE();
     tick(4 * s + 6, mp, ep);
     pvrtc_keys_row<2>(keys, mp);
     if (s >= 0 && s < K) {  // row 1 of block s, weight 3
-      pvrtc_row_mods_v<false>(V, ep, 0u, row, nullptr);
+      ICAMD_ROW_MODS(ep, row);
       acc.hc = sad_u8(prev[0], row[0], acc.hc);
       acc.hc = sad_u8(prev[1], row[1], acc.hc);
       pvrtc_acc_row<true>(acc, 1, row, 0u);
@@ -879,6 +918,98 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
     }
     ICAMD_SCHED_FENCE();
   }
+}
+#undef ICAMD_ROW_MODS
+#undef ICAMD_ROW_STEP
+
+// ---- PVRTC1 4 bpp (r05): EXTENSION, PARITY UNPINNED -- BASELINE.json's config 5 names "PVRTC 4bpp", the reference only
+// has 2 bpp (public/pvrtc_compressor.h:15-18).  The 2 bpp rules above with 4 x 4-pixel blocks, exactly as
+// oracle/ic_oracle.c (pvrtc4_encode_image) restates them: GetExtremesFast over 16 pixels, the same channel reduction,
+// BestModulation against A / B up-sampled with weights (x + 2) & 3, (y + 2) & 3 out of 4 in both directions, every pixel's
+// 2-bit value stored at bits 2 (4 y + x), colour word with bit 0 clear.
+// GetExtremesFast (pvrtc.cc:255-329) on px[4 y + x]: the keys of pvrtc_extremes with 4-bit indices.
+ICAMD_DEV void pvrtc4_extremes(const uint32_t px[16], uint32_t image0, BlockStash &stash, uint32_t &col_a, uint32_t &col_b) {
+  uint32_t kmin_l = 0xffffffffu, kmax_l = 0u, kmin_rb = 0xffffffffu, kmax_rb = 0u, kmin_ga = 0xffffffffu, kmax_ga = 0u;
+  ICAMD_UNROLL
+  for (int p = 0; p < 16; p += 2) {
+    uint32_t kl[2];
+    ICAMD_UNROLL
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t c = px[p + q], i = (uint32_t)((p + q) & 3);
+      const uint32_t idx4 = (uint32_t)((p + q) & ~3) * 0x01010101u + 0x03020100u;
+      const uint32_t up = (uint32_t)(15 - 2 * (p + q)) * 0x00010001u;  // max-side key = value * 256 + (15 - idx)
+      kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
+      const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16), k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
+      kmin_rb = pk_min_u16(kmin_rb, k_rb);
+      kmin_ga = pk_min_u16(kmin_ga, k_ga);
+      kmax_rb = pk_max_u16(kmax_rb, k_rb + up);
+      kmax_ga = pk_max_u16(kmax_ga, k_ga + up);
+    }
+    kmin_l = umin3(kmin_l, kl[0], kl[1]);
+    kmax_l = umax3(kmax_l, kl[0] + (uint32_t)(15 - 2 * p), kl[1] + (uint32_t)(15 - 2 * (p + 1)));
+  }
+  const uint32_t kmin[5] = { kmin_l, kmin_rb & 0xffffu, kmin_ga & 0xffffu, kmin_rb >> 16, kmin_ga >> 16 };
+  const uint32_t kmax[5] = { kmax_l, kmax_rb & 0xffffu, kmax_ga & 0xffffu, kmax_rb >> 16, kmax_ga >> 16 };
+  stash.put(px);
+  uint32_t best_diff = 0, best_lo = 0, best_hi = 0;
+  ICAMD_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    const uint32_t lo = stash.get(kmin[i] & 15u);
+    const uint32_t hi_block = stash.get(15u - (kmax[i] & 15u));
+    const uint32_t hi = (kmax[i] >> 8) == 0u ? image0 : hi_block;  // never-updated max -> image pixel 0 (pvrtc.cc:268-269)
+    const uint32_t d = sad_u8(lo, hi, 0u);
+    const bool better = (i == 0) || d > best_diff;
+    best_lo = better ? lo : best_lo;
+    best_hi = better ? hi : best_hi;
+    best_diff = better ? d : best_diff;
+  }
+  const bool swap = udot4(best_hi, 0x01010101u, 0u) < udot4(best_lo, 0x01010101u, 0u);
+  col_a = swap ? best_hi : best_lo;
+  col_b = swap ? best_lo : best_hi;
+}
+
+// The block's 32-bit modulation word from its pixels and the reduced colours of its 3 x 3 block neighbourhood (toroidal wrap
+// applied by the caller).  Separable like the 2 bpp walk: per pixel row the three block columns are blended vertically,
+// V = 4 ((4 - yw) top + yw bottom), then each half row walks P(xw + 1) = P(xw) + 4 (VR - VL) from P = 8 (VL + VR) (x = 0, 1:
+// left | centre, xw = 2, 3) or P = 16 VL (x = 2, 3: centre | right, xw = 0, 1) -- P = 256 x colour on 16-bit lanes
+// (<= 65 280), so accumulate_mod's "take the high bytes" is the oracle's sum / 16.
+ICAMD_DEV uint32_t pvrtc4_block_data(const uint32_t px[16], const PvrtcColors nb[3][3]) {
+  uint32_t C[3][3][4];
+  ICAMD_UNROLL
+  for (int r = 0; r < 3; ++r)
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      C[r][c][0] = pair_rb(nb[r][c].a); C[r][c][1] = pair_ga(nb[r][c].a);
+      C[r][c][2] = pair_rb(nb[r][c].b); C[r][c][3] = pair_ga(nb[r][c].b);
+    }
+  uint32_t data = 0;
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const int r0 = y < 2 ? 0 : 1;
+    const uint32_t yw = (uint32_t)((y + 2) & 3);
+    uint32_t V[3][4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] = vblend_pair(yw, C[r0][c][v], C[r0 + 1][c][v]) >> 1;  // 8 x blend -> 4 x blend
+    uint32_t acc = 0;
+    ICAMD_UNROLL
+    for (int h = 0; h < 2; ++h) {
+      uint32_t P[4], D[4];
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t vl = V[h][v], vr = V[h + 1][v];
+        D[v] = (vr - vl) << 2;
+        P[v] = h == 0 ? (vl + vr) << 3 : vl << 4;
+      }
+      acc = opaque(accumulate_mod(px[4 * y + 2 * h], P, 1u << (16 * h), acc));
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) P[v] += D[v];
+      acc = opaque(accumulate_mod(px[4 * y + 2 * h + 1], P, 1u << (16 * h + 8), acc));
+    }
+    data |= udot4(acc, 0x40100401u, 0u) << (8 * y);  // bytes (values 0..3) -> four 2-bit fields
+  }
+  return data;
 }
 
 // FromZOrder inverse (pvrtc.cc:80-86): x occupies the odd bits, y the even bits of the block index.
@@ -892,6 +1023,38 @@ ICAMD_DEV uint32_t spread_bits16(uint32_t v) {
 ICAMD_DEV uint32_t pvrtc_z_index(uint32_t bx, uint32_t by) { return spread_bits16(bx) << 1 | spread_bits16(by); }
 
 #if defined(ICAMD_HOST_EMULATION)
+static inline uint32_t spread_bits16_host(uint32_t v) {
+  v = (v | v << 8) & 0x00ff00ffu; v = (v | v << 4) & 0x0f0f0f0fu; v = (v | v << 2) & 0x33333333u; v = (v | v << 1) & 0x55555555u;
+  return v;
+}
+// PVRTC 4 bpp (extension): the device math above over a whole image (tests/host_emul only).
+static inline int emul_pvrtc4(const uint8_t *src, uint32_t n, uint8_t *out) {
+  const uint32_t lw = n / 4;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(src);
+  PvrtcColors *col = new PvrtcColors[(size_t)lw * lw];
+  for (uint32_t by = 0; by < lw; ++by)
+    for (uint32_t bx = 0; bx < lw; ++bx) {
+      uint32_t px[16], a, b;
+      for (int i = 0; i < 16; ++i) px[i] = img[(size_t)(by * 4 + i / 4) * n + bx * 4 + i % 4];
+      BlockStash st;
+      pvrtc4_extremes(px, img[0], st, a, b);
+      col[by * lw + bx].a = channel_reduce(a, false);
+      col[by * lw + bx].b = channel_reduce(b, true);
+    }
+  for (uint32_t by = 0; by < lw; ++by)
+    for (uint32_t bx = 0; bx < lw; ++bx) {
+      uint32_t px[16];
+      for (int i = 0; i < 16; ++i) px[i] = img[(size_t)(by * 4 + i / 4) * n + bx * 4 + i % 4];
+      PvrtcColors nb[3][3];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) nb[dy][dx] = col[((by + lw + dy - 1) % lw) * lw + (bx + lw + dx - 1) % lw];
+      uint32_t *o = reinterpret_cast<uint32_t *>(out) + 2 * (size_t)(spread_bits16_host(bx) << 1 | spread_bits16_host(by));
+      o[0] = pvrtc4_block_data(px, nb);
+      o[1] = pvrtc_pack_colors(nb[1][1].a, nb[1][1].b, true);  // bit 0 clear: standard modulation
+    }
+  delete[] col;
+  return 1;
+}
 // Three-pass host driver over the device math above (tests/host_emul only).
 template <int XI, int YI>
 static inline void emul_mods_xy(const uint32_t px[32], const PvrtcAB nb[3][3], uint8_t mods[32]) {

@@ -935,6 +935,109 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   return e != hipSuccess ? e : e2;
 }
 
+// ---- PVRTC1 4 bpp (r05): EXTENSION, PARITY UNPINNED (pvrtc_block.h; the reference has no 4 bpp mode) -----------------------
+// Two kernels like the 2 bpp pair, one 4 x 4 block per lane, lanes in Z ORDER (lane k of an image = block with Z index k:
+// pvrtc.cc:80-86): the 8-byte stores of both kernels are then fully coalesced, a wave covers an 8 x 8-block patch whose
+// pixel rows are 128-byte runs, and the eight neighbour blocks' colours (8 bytes each in the workspace, indexed by Z as
+// well) mostly sit in the same patch.  x +- 1 / y +- 1 are carried out on the interleaved index itself.
+struct Pvrtc4Launch {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint2 *ab;  // workspace: reduced colours, [image][z]
+  uint64_t src_image_stride, dst_image_stride;
+  uint32_t log2_n, log2_bpi, total_blocks;
+};
+__device__ __forceinline__ uint32_t compact_even_bits_dev(uint32_t v) {
+  v &= 0x55555555u;
+  v = (v | v >> 1) & 0x33333333u;
+  v = (v | v >> 2) & 0x0f0f0f0fu;
+  v = (v | v >> 4) & 0x00ff00ffu;
+  v = (v | v >> 8) & 0x0000ffffu;
+  return v;
+}
+__device__ __forceinline__ void pvrtc4_load_block(const Pvrtc4Launch &L, const uint32_t *img, uint32_t z, uint32_t px[16]) {
+  const uint32_t bx = compact_even_bits_dev(z >> 1), by = compact_even_bits_dev(z);
+  const uint32_t *p = img + (((by * 4u) << L.log2_n) + bx * 4u);
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    const U4 v = load_stream(reinterpret_cast<const U4 *>(p + ((size_t)y << L.log2_n)));
+    px[4 * y] = v.x; px[4 * y + 1] = v.y; px[4 * y + 2] = v.z; px[4 * y + 3] = v.w;
+  }
+}
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc4_morph_kernel(Pvrtc4Launch L) {
+  __shared__ uint32_t lds_px[4][kMorphLanes][4];
+  const uint32_t k = blockIdx.x * kMorphLanes + threadIdx.x;
+  if (k >= L.total_blocks) return;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)(k >> L.log2_bpi) * L.src_image_stride);
+  uint32_t px[16];
+  pvrtc4_load_block(L, img, k & ((1u << L.log2_bpi) - 1u), px);
+  BlockStash stash;
+  stash.base = &lds_px[0][threadIdx.x][0];
+  uint32_t a, c;
+  pvrtc4_extremes(px, img[0], stash, a, c);
+  L.ab[k] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+}
+extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc4_encode_kernel(Pvrtc4Launch L) {
+  const uint32_t k = blockIdx.x * kEncodeLanes + threadIdx.x;
+  if (k >= L.total_blocks) return;
+  const uint32_t image = k >> L.log2_bpi, mask = (1u << L.log2_bpi) - 1u, z = k & mask;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+  const uint2 *ab = L.ab + ((size_t)image << L.log2_bpi);
+  // toroidal neighbours on the interleaved index: x lives in the odd bits, y in the even bits
+  const uint32_t X = 0xaaaaaaaau & mask, Y = 0x55555555u & mask, zx = z & X, zy = z & Y;
+  const uint32_t xs[3] = { (zx - 1u) & X, zx, ((zx | ~X) + 1u) & X }, ys[3] = { (zy - 1u) & Y, zy, ((zy | ~Y) + 1u) & Y };
+  PvrtcColors nb[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint2 v = ab[xs[c] | ys[r]];
+      nb[r][c].a = v.x;
+      nb[r][c].b = v.y;
+    }
+  uint32_t px[16];
+  pvrtc4_load_block(L, img, z, px);
+  const uint32_t data = pvrtc4_block_data(px, nb);
+  uint8_t *dst = L.dst + (size_t)image * L.dst_image_stride + (size_t)z * 8u;
+  store_stream8(dst, data, pvrtc_pack_colors(nb[1][1].a, nb[1][1].b, true));  // bit 0 clear: standard modulation
+}
+
+hipError_t launch_pvrtc4(const PvrtcParams &P, hipStream_t stream) {
+  if (P.n_images == 0) return hipSuccess;
+  if (P.region_blocks != 0) return hipErrorInvalidValue;
+  const uint64_t bpi = (uint64_t)(P.size / 4) * (P.size / 4);
+  const uint64_t group = pvrtc_group(P.size, P.n_images);
+  if (bpi * group >= (1ull << 31)) return hipErrorInvalidValue;
+  uint2 *ab = nullptr;
+  Workspace &ws = g_tls_workspace.get();
+  hipError_t e = ws.acquire((size_t)(bpi * group * sizeof(uint2)), stream, reinterpret_cast<void **>(&ab), P.internal_workspace);
+  if (e != hipSuccess) return e;
+  (void)hipGetLastError();
+  for (uint64_t first = 0; first < P.n_images; first += group) {
+    const uint64_t count = (P.n_images - first < group) ? P.n_images - first : group;
+    Pvrtc4Launch L;
+    L.src = P.src + first * P.src_image_stride;
+    L.dst = P.dst + first * P.dst_image_stride;
+    L.ab = ab;
+    L.src_image_stride = P.src_image_stride;
+    L.dst_image_stride = P.dst_image_stride;
+    L.log2_n = P.log2_size;
+    L.log2_bpi = 2 * P.log2_size - 4;
+    L.total_blocks = (uint32_t)(bpi * count);
+    const dim3 grid((L.total_blocks + kMorphLanes - 1) / kMorphLanes);
+    hipLaunchKernelGGL(icamd_pvrtc4_morph_kernel, grid, dim3(kMorphLanes), 0, stream, L);
+    hipLaunchKernelGGL(icamd_pvrtc4_encode_kernel, grid, dim3(kEncodeLanes), 0, stream, L);
+  }
+  e = hipGetLastError();
+  const hipError_t e2 = ws.release(stream);
+  return e != hipSuccess ? e : e2;
+}
+size_t pvrtc4_workspace_bytes(uint32_t size, uint32_t n_images) {
+  if (n_images == 0) return 0;
+  return (size_t)((uint64_t)(size / 4) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));
+}
+const char *pvrtc4_kernel_name() { return "icamd_pvrtc4_encode_kernel"; }
+
 size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images) {
   if (n_images == 0) return 0;
   return (size_t)((uint64_t)(size / 8) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));

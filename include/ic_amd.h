@@ -37,7 +37,14 @@ enum { ICAMD_ETC_SPLIT_HORIZONTALLY = 0, ICAMD_ETC_SPLIT_VERTICALLY = 1,
 
 /* Block codec actually written (the reference derives it from compressor + format,
  * internal/dxtc_compressor.cc:741-749). */
-enum { ICAMD_DXT1 = 0, ICAMD_DXT5 = 1, ICAMD_ETC1 = 2, ICAMD_PVRTC2 = 3 };
+enum { ICAMD_DXT1 = 0, ICAMD_DXT5 = 1, ICAMD_ETC1 = 2, ICAMD_PVRTC2 = 3,
+       /* EXTENSION, PARITY UNPINNED: PVRTC1 4 bpp (4 x 4-pixel blocks, 64 bits each).  BASELINE.json's config 5 names it, the
+        * reference only implements 2 bpp (public/pvrtc_compressor.h:15-18), so it is written from the reference's 2 bpp rules
+        * (pvrtc_compressor.cc:111-349) with the block shape changed, and checked against oracle/ic_oracle.c's restatement of the
+        * same rules and by decoding.  Accepted by icamd_encode_device (RGBA8, square power of two >= 8, no row padding:
+        * size * size / 2 bytes per image, blocks in the 2 bpp Z order) and icamd_encoded_size only; under stream capture it needs a
+        * caller workspace of icamd_pvrtc4_workspace_size bytes (icamd_pvrtc2_set_workspace). */
+       ICAMD_PVRTC4 = 4 };
 
 /* Status codes.  0 = the reference's `true`; 1 = the reference's `false` (argument
  * validation, unsupported format, external-storage size mismatch); < 0 = the device
@@ -102,6 +109,7 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
  * calls that follow on THIS thread; the caller keeps it alive and exclusive for as long as work (or a graph) using it
  * can run, one per graph.  NULL returns to the internal buffer. */
 size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images);
+size_t icamd_pvrtc4_workspace_size(uint32_t size, uint32_t n_images); /* the same for ICAMD_PVRTC4 (extension) */
 int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes);
 
 /* PVRTC kernel selection (EXTENSION, tuning / test hook; results are identical either way).  Whole textures of 512^2 ...

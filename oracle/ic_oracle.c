@@ -553,6 +553,87 @@ static int pvrtc_encode_image(const uint8_t *img, uint32_t w, uint32_t h, uint8_
   return 1;
 }
 
+/* ---- PVRTC1 4 bpp encoder: EXTENSION, PARITY UNPINNED.  BASELINE.json's config 5 names "PVRTC 4bpp"; the reference only
+ * implements 2 bpp (public/pvrtc_compressor.h:15-18), so there is nothing to pin this against.  It is the
+ * reference's 2 bpp encoder with the block shape changed, rule by rule:
+ *   - blocks are 4 x 4 pixels; Morph (pvrtc.cc:506-521): GetExtremesFast (:255-329, incl. the image-pixel-0 initialisation of
+ *     the maxima, :268-269) over the block's 16 pixels in raster order, ApplyColorChannelReduction (:337-349) unchanged;
+ *   - Modulate (pvrtc.cc:527-540): BestModulation (:148-166, early exit) against the A / B images up-sampled like
+ *     GetInterpolatedColor2BPP (:208-237) with the 4 bpp geometry -- block centres at (2, 2), weights (x + 2) & 3 and
+ *     (y + 2) & 3 out of 4 in BOTH directions, toroidal wrap, sum / 16;
+ *   - Encode: every pixel keeps its 2-bit value, pixel (x, y) at bits 2 (4 y + x) of the modulation word (PVRTC1 4 bpp block
+ *     layout); colour word = EncodeColors (pvrtc.cc:356-388) with bit 0 (the modulation-mode flag of a 4 bpp block) clear:
+ *     standard weights 0, 3/8, 5/8, 1 -- the only ones ApplyModulation (:120-144) has; blocks in the same Z order
+ *     (pvrtc.cc:80-86: x in the odd bits). */
+static void pvrtc4_extremes(const uint8_t *img, uint32_t w, uint32_t x0, uint32_t y0, uint32_t *ia, uint32_t *ib) {
+  uint32_t fit[5][2], idx[5][2];
+  for (int i = 0; i < 5; ++i) { fit[i][0] = 0xffffffffu; fit[i][1] = 0; idx[i][0] = idx[i][1] = 0; }
+  for (uint32_t y = y0; y < y0 + 4; ++y)
+    for (uint32_t x = x0; x < x0 + 4; ++x) {
+      uint32_t index = y * w + x;
+      rgba_t c = load_rgba(img, index);
+      uint32_t v[5] = { (77u * c.r + 150u * c.g + 28u * c.b) / 256u, c.r, c.g, c.b, c.a };
+      for (int i = 0; i < 5; ++i) {
+        if (v[i] < fit[i][0]) { fit[i][0] = v[i]; idx[i][0] = index; }
+        if (v[i] > fit[i][1]) { fit[i][1] = v[i]; idx[i][1] = index; }
+      }
+    }
+  uint32_t best_diff = 0, best = 0;
+  for (uint32_t i = 0; i < 5; ++i) {
+    uint32_t d = color_diff(load_rgba(img, idx[i][0]), load_rgba(img, idx[i][1]));
+    if (d > best_diff) { best = i; best_diff = d; }
+  }
+  uint32_t a = idx[best][0], b = idx[best][1];
+  rgba_t ca = load_rgba(img, a), cb = load_rgba(img, b);
+  if ((uint32_t)cb.r + cb.g + cb.b + cb.a < (uint32_t)ca.r + ca.g + ca.b + ca.a) { uint32_t t = a; a = b; b = t; }
+  *ia = a; *ib = b;
+}
+static rgba_t pvrtc4_interp(const rgba_t *low, uint32_t n, uint32_t x, uint32_t y) {
+  uint32_t lw = n / 4, left = ((x - 2) & (n - 1)) >> 2, top = ((y - 2) & (n - 1)) >> 2;
+  uint32_t right = (left + 1) & (lw - 1), bottom = (top + 1) & (lw - 1);
+  uint32_t px = (x + 2) & 3, py = (y + 2) & 3;
+  rgba_t c00 = low[top * lw + left], c01 = low[top * lw + right], c10 = low[bottom * lw + left], c11 = low[bottom * lw + right];
+  uint32_t a = (4 - py) * (4 - px), b = (4 - py) * px, c = py * (4 - px), d = py * px;
+  rgba_t o;
+  o.r = (uint8_t)((a * c00.r + b * c01.r + c * c10.r + d * c11.r) / 16);
+  o.g = (uint8_t)((a * c00.g + b * c01.g + c * c10.g + d * c11.g) / 16);
+  o.b = (uint8_t)((a * c00.b + b * c01.b + c * c10.b + d * c11.b) / 16);
+  o.a = (uint8_t)((a * c00.a + b * c01.a + c * c10.a + d * c11.a) / 16);
+  return o;
+}
+static int pvrtc4_encode_image(const uint8_t *img, uint32_t n, uint8_t *out) {
+  uint32_t lw = n / 4, nblocks = lw * lw;
+  rgba_t *la = (rgba_t *)malloc(sizeof(rgba_t) * nblocks), *lb = (rgba_t *)malloc(sizeof(rgba_t) * nblocks);
+  if (!la || !lb) { free(la); free(lb); return 0; }
+  for (uint32_t by = 0; by < lw; ++by)
+    for (uint32_t bx = 0; bx < lw; ++bx) {
+      uint32_t ia, ib;
+      pvrtc4_extremes(img, n, bx * 4, by * 4, &ia, &ib);
+      la[by * lw + bx] = channel_reduce(load_rgba(img, ia), 0);
+      lb[by * lw + bx] = channel_reduce(load_rgba(img, ib), 1);
+    }
+  for (uint32_t i = 0; i < nblocks; ++i) {
+    uint32_t bx = 0, by = 0;
+    for (int j = 0; j < 16; ++j) { /* pvrtc.cc:80-86 */
+      bx |= ((i >> (2 * j + 1)) & 1u) << j;
+      by |= ((i >> (2 * j)) & 1u) << j;
+    }
+    uint32_t data = 0;
+    for (uint32_t y = 0; y < 4; ++y)
+      for (uint32_t x = 0; x < 4; ++x) {
+        uint32_t xx = bx * 4 + x, yy = by * 4 + y;
+        uint32_t m = pvrtc_best_mod(load_rgba(img, yy * n + xx), pvrtc4_interp(la, n, xx, yy), pvrtc4_interp(lb, n, xx, yy));
+        data |= m << (2 * (4 * y + x));
+      }
+    uint32_t colors = pvrtc_pack_colors(la[by * lw + bx], lb[by * lw + bx], 1 /* bit 0 clear: standard modulation */);
+    uint8_t *o = out + (size_t)i * 8;
+    o[0] = (uint8_t)data; o[1] = (uint8_t)(data >> 8); o[2] = (uint8_t)(data >> 16); o[3] = (uint8_t)(data >> 24);
+    o[4] = (uint8_t)colors; o[5] = (uint8_t)(colors >> 8); o[6] = (uint8_t)(colors >> 16); o[7] = (uint8_t)(colors >> 24);
+  }
+  free(la); free(lb);
+  return 1;
+}
+
 /* ------------------------------------------------------------ public API -- */
 
 static uint32_t nblk(uint32_t n) { return (n + 3) / 4; } /* helper.h:86-88 */
@@ -560,6 +641,7 @@ static int is_pow2(uint32_t x) { return x != 0 && !(x & (x - 1)); }
 
 size_t ico_encoded_size(int codec, uint32_t gh, uint32_t gw) {
   if (codec == ICO_PVRTC2) return (size_t)gw * gh / 4;
+  if (codec == ICO_PVRTC4) return (size_t)gw * gh / 2;
   return (size_t)nblk(gh) * nblk(gw) * block_bytes(codec);
 }
 
@@ -570,6 +652,10 @@ int ico_encode(int codec, int etc_strategy, int comps, int swap, uint32_t h, uin
     /* pvrtc.cc:636-667 preconditions; source is always read as RGBA8888 */
     if (!is_pow2(w) || !is_pow2(h) || w != h || w % 8 || h % 4 || comps != 4 || stride != w * 4) return 0;
     return pvrtc_encode_image(src, w, h, out);
+  }
+  if (codec == ICO_PVRTC4) { /* extension: the same preconditions (square power of two, at least 8, RGBA8, no row padding) */
+    if (!is_pow2(w) || w != h || w < 8 || comps != 4 || stride != w * 4) return 0;
+    return pvrtc4_encode_image(src, w, out);
   }
   if (codec != ICO_DXT1 && codec != ICO_DXT5 && codec != ICO_ETC1) return 0;
   if (codec == ICO_DXT5 && comps != 4) return 0;
@@ -798,12 +884,48 @@ static int pvrtc_decode_image(const uint8_t *blocks, uint32_t n, uint8_t *out) {
   return 1;
 }
 
+/* PVRTC1 4 bpp decoder (extension, parity unpinned like the encoder above): the inverse of pvrtc4_encode_image -- colours
+ * unpacked like the 2 bpp decoder's, A / B up-sampled with pvrtc4_interp, pixel = ((8 - w) A + w B) >> 3 with w = 0, 3, 5, 8
+ * (ApplyModulation, pvrtc.cc:120-144).  A block whose mode flag (colour word bit 0) is set uses PVRTC1's punch-through
+ * weights 0, 4, 4, 8 with alpha 0 for value 2; the encoder never produces it. */
+static int pvrtc4_decode_image(const uint8_t *blocks, uint32_t n, uint8_t *out) {
+  uint32_t lw = n / 4, nblocks = lw * lw;
+  rgba_t *la = (rgba_t *)malloc(sizeof(rgba_t) * nblocks), *lb = (rgba_t *)malloc(sizeof(rgba_t) * nblocks);
+  uint32_t *data = (uint32_t *)malloc(sizeof(uint32_t) * nblocks);
+  uint8_t *punch = (uint8_t *)malloc(nblocks);
+  if (!la || !lb || !data || !punch) { free(la); free(lb); free(data); free(punch); return 0; }
+  for (uint32_t by = 0; by < lw; ++by)
+    for (uint32_t bx = 0; bx < lw; ++bx) {
+      const uint8_t *p = blocks + 8 * (size_t)pvrtc_z_of(bx, by);
+      uint32_t c = (uint32_t)p[4] | (uint32_t)p[5] << 8 | (uint32_t)p[6] << 16 | (uint32_t)p[7] << 24;
+      data[by * lw + bx] = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+      punch[by * lw + bx] = (uint8_t)(c & 1u);
+      la[by * lw + bx] = pvrtc_unpack_a(c); lb[by * lw + bx] = pvrtc_unpack_b(c);
+    }
+  for (uint32_t y = 0; y < n; ++y)
+    for (uint32_t x = 0; x < n; ++x) {
+      uint32_t blk = (y >> 2) * lw + (x >> 2), m = (data[blk] >> (2 * (4 * (y & 3) + (x & 3)))) & 3u;
+      int w = punch[blk] ? (m == 0 ? 0 : m == 3 ? 8 : 4) : kPvWeight[m];
+      rgba_t a = pvrtc4_interp(la, n, x, y), b = pvrtc4_interp(lb, n, x, y);
+      uint8_t *o = out + 4 * ((size_t)y * n + x);
+      o[0] = (uint8_t)(((8 - w) * a.r + w * b.r) >> 3); o[1] = (uint8_t)(((8 - w) * a.g + w * b.g) >> 3);
+      o[2] = (uint8_t)(((8 - w) * a.b + w * b.b) >> 3); o[3] = (uint8_t)(((8 - w) * a.a + w * b.a) >> 3);
+      if (punch[blk] && m == 2) o[3] = 0;
+    }
+  free(la); free(lb); free(data); free(punch);
+  return 1;
+}
+
 /* helper.h:218-262 */
 int ico_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const uint8_t *blocks, uint8_t *out) {
   if (!blocks || !out || h == 0 || w == 0) return 0;
   if (codec == ICO_PVRTC2) { /* extension, see above; same size rules as PvrtcCompressor::Compress, pvrtc.cc:636-650 */
     if (h != w || !is_pow2(w) || w < 8 || pad != 0) return 0;
     return pvrtc_decode_image(blocks, w, out);
+  }
+  if (codec == ICO_PVRTC4) { /* extension */
+    if (h != w || !is_pow2(w) || w < 8 || pad != 0) return 0;
+    return pvrtc4_decode_image(blocks, w, out);
   }
   if (codec != ICO_DXT1 && codec != ICO_DXT5 && codec != ICO_ETC1) return 0;
   int comps = codec == ICO_DXT5 ? 4 : 3;

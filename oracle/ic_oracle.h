@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 /* Block codecs (what is written), independent of the reference's class split. */
-enum { ICO_DXT1 = 0, ICO_DXT5 = 1, ICO_ETC1 = 2, ICO_PVRTC2 = 3 };
+enum { ICO_DXT1 = 0, ICO_DXT5 = 1, ICO_ETC1 = 2, ICO_PVRTC2 = 3,
+       ICO_PVRTC4 = 4 /* EXTENSION, parity unpinned: PVRTC1 4 bpp written from the 2 bpp rules (ic_oracle.c) */ };
 
 /* Reference compressor classes and CompressedImage::Format (compressed_image.h:35-40). */
 enum { ICO_COMPRESSOR_DXTC = 0, ICO_COMPRESSOR_ETC = 1, ICO_COMPRESSOR_PVRTC = 2 };

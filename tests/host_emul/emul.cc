@@ -20,6 +20,7 @@ using namespace icamd;
 extern "C" int emul_encode(int codec, int strategy, int comps, int swap, uint32_t h, uint32_t w, uint32_t gh,
                            uint32_t gw, uint32_t stride, const uint8_t *src, uint8_t *out) {
   if (codec == 3) return emul_pvrtc2(src, w, out);
+  if (codec == 4) return emul_pvrtc4(src, w, out);
   const uint32_t rows = (std::max(h, gh) + 3) / 4, cols = (std::max(w, gw) + 3) / 4;
   for (uint32_t br = 0; br < rows; ++br)
     for (uint32_t bc = 0; bc < cols; ++bc) {

@@ -17,6 +17,7 @@ REF_SO = os.path.join(ORACLE_DIR, "_ref", "libic_ref.so")
 
 # block codecs (oracle/ic_oracle.h, include/ic_amd.h use the same numbering)
 DXT1, DXT5, ETC1, PVRTC2 = 0, 1, 2, 3
+PVRTC4 = 4  # extension, parity unpinned (the reference has no 4 bpp mode)
 # reference compressor classes / formats / ETC strategies
 DXTC, ETC, PVRTC = 0, 1, 2
 RGB, BGR, RGBA, BGRA = 0, 1, 2, 3
@@ -125,7 +126,7 @@ def oracle_encode(codec, src, h, w, comps, swap=0, strategy=SMALLER_ERROR, gh=No
 
 
 def oracle_decode(codec, blocks, h, w, swap=0, pad=0):
-    comps = 4 if codec in (DXT5, PVRTC2) else 3
+    comps = 4 if codec in (DXT5, PVRTC2, PVRTC4) else 3
     out = np.zeros(h * (w * comps + pad), np.uint8)
     b = np.frombuffer(blocks, np.uint8)
     ok = oracle().ico_decode(codec, swap, h, w, pad, _ptr(b), _ptr(out))

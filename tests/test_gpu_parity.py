@@ -361,6 +361,46 @@ def test_pvrtc_onepass_kernel_every_strip_height_matches_oracle(pkg, pvrtc_auto)
             assert not host[off + (cnt - 1) * dst_stride + per:].any() and not host[:off].any()
 
 
+def test_pvrtc4_extension_matches_the_oracles_restatement_and_decodes(pkg):
+    """PVRTC1 4 bpp (EXTENSION, parity unpinned: BASELINE config 5 names it, the reference has none): the device kernels
+    against oracle/ic_oracle.c's restatement of the same rules (8^2 ... 4096^2, all contents, the image-pixel-0 rule, batches
+    with padded strides), and the decoded result against the source (the only outside check there is)."""
+    import torch
+    for n in (8, 16, 32, 64, 256, 1024):
+        for gen in ("noise", "smooth", "flat", "mixed"):
+            img = T.GENERATORS[gen](n, n, 4, index=n + 9)
+            out = pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4)
+            assert _host(out) == T.oracle_encode(T.PVRTC4, img, n, n, 4), (n, gen)
+    img = np.zeros((32, 32, 4), np.uint8)
+    img[0, 0] = (250, 3, 7, 255)
+    img[8:, :, 1] = 200
+    img[:, 16:, 3] = 255
+    assert _host(pkg.encode_device(T.PVRTC4, _dev(img), 32, 32, 4)) == T.oracle_encode(T.PVRTC4, img, 32, 32, 4)
+    n, cnt = 512, 5
+    imgs = np.stack([T.s_mixed(n, n, 4, index=70 + i) for i in range(cnt)])
+    src = torch.zeros((cnt, n * n * 4 + 64), dtype=torch.uint8, device="cuda")
+    src[:, : n * n * 4] = _dev(imgs).view(cnt, -1)
+    per = n * n // 2
+    out = torch.zeros((cnt, per + 24), dtype=torch.uint8, device="cuda")
+    assert pkg.lib().icamd_encode_device(T.PVRTC4, 2, 4, 0, n, n, n, n, n * 4, cnt, n * n * 4 + 64, per + 24, src.data_ptr(),
+                                         out.data_ptr(), None) == pkg.OK
+    torch.cuda.synchronize()
+    for i in range(cnt):
+        assert out[i, :per].cpu().numpy().tobytes() == T.oracle_encode(T.PVRTC4, imgs[i], n, n, 4), i
+        assert not out[i, per:].any()
+    n = 4096
+    img = T.s_smooth(n, n, 4, index=21)
+    img[:1024, :1024] = T.s_noise(1024, 1024, 4, index=21)
+    got = _host(pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4))
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(T.oracle_encode(T.PVRTC4, img, n, n, 4)).hexdigest()
+    dec = T.oracle_decode(T.PVRTC4, got, n, n).reshape(n, n, 4).astype(np.float64)
+    mse = float(((dec[1024:] - img[1024:].astype(np.float64)) ** 2).mean())
+    assert 10 * np.log10(255.0 * 255.0 / mse) > 18.0  # the smooth part (ramps + 5-bit noise + random alpha)
+    assert pkg.encoded_size(T.PVRTC4, 64, 64) == 2048 and pkg.pvrtc4_workspace_size(64, 3) == 3 * 256 * 8
+    assert pkg.lib().icamd_encode_device(T.PVRTC4, 2, 4, 0, 16, 32, 16, 32, 128, 1, 0, 0, src.data_ptr(), out.data_ptr(), None) == pkg.FALSE
+    assert pkg.lib().icamd_encode_device(T.PVRTC4, 2, 3, 0, 16, 16, 16, 16, 48, 1, 0, 0, src.data_ptr(), out.data_ptr(), None) == pkg.FALSE
+
+
 def test_pvrtc_automatic_path_selection_and_both_paths_on_a_full_batch(pkg, pvrtc_auto):
     """The launch shapes BASELINE config 5 is quoted on (16 x 4096^2) and its neighbours: the automatic selection, the
     forced pair and the forced one-pass kernel produce the same bytes; texture 0 and the last one against the oracle."""
@@ -890,7 +930,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
     d = _run_bench(["--steps", "3", "--warmup", "1", "--extra-steps", "2", "--no-sustained", "--no-single-image", "--no-host-api",
                     "--no-cpu-baseline", "--precondition-seconds", "0"], timeout=900)
     assert d["config"]["preset"] == "c2" and d["parity"].startswith("bit-exact")
-    assert sorted(d["configs"]) == ["c3", "c4", "c5"]
+    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp"]
     for name, leg in d["configs"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, (name, leg)
     assert d["configs"]["c4"]["textures_per_gpu_per_step"] == 1024 and d["configs"]["c4"]["etc_strategy"] == 2
@@ -931,7 +971,7 @@ def test_bench_rehearsal_of_the_drivers_eight_rank_command(pkg):
     lp = d["link_probe"]
     assert lp["peers"] == 7 and len(lp["per_peer_alone_GBps"]) == 7 and lp["payload_intact"] and lp["xgmi_links_into_rank0"] == 7
     assert "value_with_gather_ceiling" in d["scaling_headline"]
-    assert sorted(d["configs"]) == ["c3", "c4", "c5"]
+    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp"]
     for name, leg in d["configs"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
         assert leg["rank0_copy_matches"] is True and leg["gather_ranks"] == 8 and leg["gather_bound_GBps"] > 0, (name, leg)

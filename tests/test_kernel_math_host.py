@@ -132,6 +132,49 @@ def test_pvrtc_math_matches_oracle(emul):
     assert emul_encode(emul, T.PVRTC2, img, 32, 32, 4) == T.oracle_encode(T.PVRTC2, img, 32, 32, 4)
 
 
+def test_pvrtc4_math_matches_oracle(emul):
+    """PVRTC 4 bpp (extension, parity unpinned): the device block math (pvrtc4_extremes, pvrtc4_block_data) against the
+    oracle's restatement of the same rules -- two independent forms of one specification, not a reference check."""
+    for n in (8, 16, 32, 64, 128):
+        for gen in ("noise", "smooth", "flat", "mixed"):
+            img = T.GENERATORS[gen](n, n, 4, index=n + 4)
+            assert emul_encode(emul, T.PVRTC4, img, n, n, 4) == T.oracle_encode(T.PVRTC4, img, n, n, 4), (n, gen)
+    img = np.zeros((32, 32, 4), np.uint8)  # never-updated maxima refer to image pixel 0
+    img[0, 0] = (250, 3, 7, 255)
+    img[8:, :, 1] = 200
+    img[:, 16:, 3] = 255
+    assert emul_encode(emul, T.PVRTC4, img, 32, 32, 4) == T.oracle_encode(T.PVRTC4, img, 32, 32, 4)
+
+
+def test_pvrtc4_round_trip_properties():
+    """What ties the (reference-less) 4 bpp pair to the format: a solid texture decodes to the encoder's channel-reduced
+    colour; a clean gradient survives at high PSNR; 4 bpp is at least as close to the source as 2 bpp on every content."""
+    def psnr(a, b):
+        mse = float(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean())
+        return 99.0 if mse == 0 else 10 * np.log10(255.0 * 255.0 / mse)
+    n = 64
+    # colour A keeps R5 G5 B4, colour B R5 G5 B5 of an opaque colour (pvrtc.cc:337-349): a solid texture decodes to ONE colour
+    # that lies between the two reduced colours and is never further from the source than colour A
+    for colour, red_a, red_b in (((200, 100, 50, 255), (206, 99, 51, 255), (206, 99, 49, 255)),
+                                 ((16, 255, 0, 255), (16, 255, 0, 255), (16, 255, 0, 255))):
+        img = np.empty((n, n, 4), np.uint8)
+        img[:] = colour
+        dec = T.oracle_decode(T.PVRTC4, T.oracle_encode(T.PVRTC4, img, n, n, 4), n, n).reshape(-1, 4)
+        assert (dec == dec[0]).all()
+        got = [int(v) for v in dec[0]]
+        assert all(min(a, b) <= g <= max(a, b) for g, a, b in zip(got, red_a, red_b)), got
+        assert sum(abs(g - c) for g, c in zip(got, colour)) <= sum(abs(a - c) for a, c in zip(red_a, colour)), got
+    y, x = np.mgrid[0:n, 0:n]
+    ramp = np.stack([2 * x + 60, 2 * y + 40, x + y + 30, np.full_like(x, 255)], axis=-1).astype(np.uint8)
+    dec = T.oracle_decode(T.PVRTC4, T.oracle_encode(T.PVRTC4, ramp, n, n, 4), n, n).reshape(n, n, 4)
+    assert psnr(dec, ramp) > 30.0, psnr(dec, ramp)
+    for gen in ("noise", "smooth", "flat", "mixed"):
+        img = T.GENERATORS[gen](256, 256, 4, index=3)
+        d4 = T.oracle_decode(T.PVRTC4, T.oracle_encode(T.PVRTC4, img, 256, 256, 4), 256, 256).reshape(256, 256, 4)
+        d2 = T.oracle_decode(T.PVRTC2, T.oracle_encode(T.PVRTC2, img, 256, 256, 4), 256, 256).reshape(256, 256, 4)
+        assert psnr(d4, img) > psnr(d2, img), gen
+
+
 def test_decode_math_matches_oracle(emul):
     emul.emul_decode.restype = ctypes.c_int
     emul.emul_decode.argtypes = [T.ci, T.ci, T.u32, T.u32, T.u32, T.vp, T.vp]
