@@ -35,4 +35,4 @@ def test_explicit_flags_leave_the_presets():
     a = b.parse_args(["--config", "c4", "--batch", "7"])  # an explicit batch turns config 4 into a weak-scaling run
     assert (a.total_textures, a.batch) == (None, 7)
     for wl, (codec, comps, bpp, label, unit) in b.WORKLOADS.items():
-        assert unit in ("hbm", "valu") and bpp == comps + {0: 0.5, 1: 1.0, 2: 0.5, 3: 0.25}[codec]
+        assert unit in ("hbm", "valu") and bpp == comps + {0: 0.5, 1: 1.0, 2: 0.5, 3: 0.25, 4: 0.5}[codec]  # 4: PVRTC 4 bpp (extension)
