@@ -70,7 +70,39 @@ __device__ __forceinline__ Out8 etc1_encode_classified(const uint32_t px[16], bo
 #ifndef ICAMD_ETC1_WAVE_8X8
 #define ICAMD_ETC1_WAVE_8X8 0
 #endif
+// ICAMD_ETC1_WAVE_WORKGROUPS (r05, default): every WAVE of a tile is a workgroup of its own (64 lanes; blockIdx.x = 4 x tile
+// column + wave).  Same tiles, same waves, same content per wave -- but a wave no longer shares its workgroup's fate.  The
+// search's cost depends on the content (shortcuts, pruning, one-colour forms are decided per wave), and a four-wave workgroup
+// is only replaced as a whole: on smooth 1024^2 textures the PMC counters showed 2.5 resident waves per SIMD of 4
+// (SQ_WAVE_CYCLES; noise: 3.7) while every resident wave issued as on noise.  A/B (profiles/r05_ab_etc1_wave_workgroups.log):
+// c4 smooth 143 -> 182, flat 345 -> 433 Gpix/s, 16 x 4096^2 smooth 182 -> 200, flat 337 -> 418, noise 253 -> 254 (= 0):
+// what three rounds of instruction-level work on the smooth case (r03 / r04) could not move was an occupancy effect.
+#ifndef ICAMD_ETC1_WAVE_WORKGROUPS
+#define ICAMD_ETC1_WAVE_WORKGROUPS 1
+#endif
+#if ICAMD_ETC1_WAVE_WORKGROUPS && ICAMD_ETC1_REGROUP
+#error "ICAMD_ETC1_REGROUP exchanges blocks between the four waves of a tile: it needs ICAMD_ETC1_WAVE_WORKGROUPS=0"
+#endif
+// (kHeuristic has no content-dependent path: it keeps the four-wave workgroups, whose dispatch costs a quarter as much)
+constexpr bool etc1_wave_workgroups(int strategy) { return ICAMD_ETC1_WAVE_WORKGROUPS != 0 && strategy != 3; }
+template <int STRATEGY>
 __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
+  if (etc1_wave_workgroups(STRATEGY)) {
+  TileCoord t;
+  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
+  const uint32_t vt = threadIdx.x + 64u * (blockIdx.x & 3u);
+  t.lx = vt & (cols - 1u);
+  t.ly = vt >> P.log2_tile_cols;
+  t.bcol0 = (blockIdx.x >> 2) * cols;
+  t.brow0 = (blockIdx.y + P.tile_row0) * rows;
+  t.bcol = t.bcol0 + t.lx;
+  t.brow = t.brow0 + t.ly;
+  t.img = blockIdx.z;
+  t.full = t.bcol0 + cols <= P.block_cols && t.brow0 + rows <= P.block_rows;
+  t.interior = (t.bcol0 + cols) * 4u <= P.width && (t.brow0 + rows) * 4u <= P.height;
+  t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
+  return t;
+  }
   TileCoord t = locate_tile<false>(P);
   if (ICAMD_ETC1_WAVE_8X8 && P.log2_tile_cols == 4u) {
     const uint32_t tid = threadIdx.x;
@@ -85,7 +117,7 @@ __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
 
 template <int COMPS, int STRATEGY>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = etc1_locate_tile(P);
+  const TileCoord t = etc1_locate_tile<STRATEGY>(P);
   if (STRATEGY == 3 || !ICAMD_ETC1_REGROUP) {
     if (!t.valid) return;
     uint32_t px[16];
@@ -210,7 +242,7 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
     { icamd_etc1_rgb888_split_h_kernel, icamd_etc1_rgb888_split_v_kernel, icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_heuristic_kernel },
     { icamd_etc1_rgba8_split_h_kernel, icamd_etc1_rgba8_split_v_kernel, icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_heuristic_kernel } };
   const Kernel k = kernels[comps == 4 ? 1 : 0][P.etc_strategy < 4u ? P.etc_strategy : 2u];
-  return launch_tiled(k, k, P, stream, cap);
+  return launch_tiled(k, k, P, stream, cap, 1, etc1_wave_workgroups(P.etc_strategy < 4u ? (int)P.etc_strategy : 2));
 }
 
 }  // namespace icamd

@@ -23,8 +23,10 @@ inline uint32_t tile_log2_cols(uint32_t block_cols) {
 // max_log2_cols < 8 asks for squarer tiles (e.g. 4: 16 x 16 blocks, a wave = 16 x 4 blocks = 64 x 16 pixels):
 // worse coalescing, but the lanes of a wave see more homogeneous content, which is what wave-uniform shortcuts need.
 template <typename Kernel>
+// wave_workgroups: every wave of a tile is launched as its own 64-lane workgroup (grid.x = 4 x column tiles; the kernel
+// undoes it: etc1_locate_tile)
 hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream,
-                        uint32_t max_log2_cols = 8, uint32_t wide_rows = 1) {
+                        uint32_t max_log2_cols = 8, uint32_t wide_rows = 1, bool wave_workgroups = false) {
   if (P.n_images == 0 || P.block_rows == 0 || P.block_cols == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
   if (P.log2_tile_cols > max_log2_cols) P.log2_tile_cols = max_log2_cols;
@@ -46,8 +48,8 @@ hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, 
       Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
       Q.tile_row0 = row0;
       const uint32_t gyc = gy - row0 < 65535u ? gy - row0 : 65535u;
-      hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(gx, gyc, count),
-                         dim3(kThreadsPerWorkgroup), 0, stream, Q);
+      hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(wave_workgroups ? gx * 4u : gx, gyc, count),
+                         dim3(wave_workgroups ? 64 : kThreadsPerWorkgroup), 0, stream, Q);
     }
   }
   return hipGetLastError();
