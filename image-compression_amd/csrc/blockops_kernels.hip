@@ -154,18 +154,26 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
   else store_stream8(dst, out[0], out[1]);
 }
 
+// Lanes per workgroup: the kernels that run an ETC1 codeword SEARCH per output block (Downsample and the Pad border with
+// kSplitHorizontally / kSplitVertically / kSmallerError) are launched as one-wave workgroups like the encoders (r05,
+// etc1_kernels.hip ICAMD_ETC1_WAVE_WORKGROUPS: the search's cost depends on the content, and a four-wave workgroup holds its
+// slots until its slowest wave is done); everything else keeps 256.
+constexpr int blockop_lanes(int codec, int strategy, int part) {
+  return (codec == ICAMD_ETC1 && strategy != 3 && part != 1) ? 64 : kThreadsPerWorkgroup;
+}
 #define ICAMD_PAD_KERNEL(NAME, CODEC, STRATEGY, PART)                                                          \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pad_##NAME##_kernel(BlockOpParams P) { \
-    const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
+    const uint32_t k = blockIdx.x * (uint32_t)blockop_lanes(CODEC, STRATEGY, PART) + threadIdx.x;              \
     if (k < P.total_out) pad_one<CODEC, STRATEGY, PART>(P, k);                                                 \
   }
 #define ICAMD_DOWNSAMPLE_KERNEL(NAME, CODEC, STRATEGY)                                                         \
   extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup)                                           \
   icamd_downsample_##NAME##_kernel(BlockOpParams P) {                                                          \
-    __shared__ uint32_t lds_px[4][kThreadsPerWorkgroup][4];                                                    \
+    /* the per-lane pixel stash is only used by the DXT colour encoder */                                      \
+    __shared__ uint32_t lds_px[CODEC == ICAMD_ETC1 ? 1 : 4][CODEC == ICAMD_ETC1 ? 1 : kThreadsPerWorkgroup][4]; \
     BlockStash stash;                                                                                          \
-    stash.base = &lds_px[0][threadIdx.x][0];                                                                   \
-    const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;                                        \
+    stash.base = CODEC == ICAMD_ETC1 ? &lds_px[0][0][0] : &lds_px[0][threadIdx.x][0];                          \
+    const uint32_t k = blockIdx.x * (uint32_t)blockop_lanes(CODEC, STRATEGY, 0) + threadIdx.x;                 \
     if (k < P.total_out) downsample_one<CODEC, STRATEGY>(P, k, stash);                                         \
   }
 
@@ -205,11 +213,12 @@ hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
     B.div_out_per_image = make_fastdiv(border ? (uint32_t)border : 1u);
     B.total_out = (uint32_t)(border * P.n_images);
     if (border) {
-      const dim3 bgrid((B.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup);
-      if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_h_kernel, bgrid, block, 0, stream, B);
-      else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_v_kernel, bgrid, block, 0, stream, B);
-      else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_pad_etc1_border_heuristic_kernel, bgrid, block, 0, stream, B);
-      else hipLaunchKernelGGL(icamd_pad_etc1_border_kernel, bgrid, block, 0, stream, B);
+      const uint32_t lanes = (uint32_t)blockop_lanes(ICAMD_ETC1, P.etc_strategy == 3u ? 3 : 2, 2);
+      const dim3 bgrid((B.total_out + lanes - 1) / lanes), bblock(lanes);
+      if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_h_kernel, bgrid, bblock, 0, stream, B);
+      else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_pad_etc1_border_split_v_kernel, bgrid, bblock, 0, stream, B);
+      else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_pad_etc1_border_heuristic_kernel, bgrid, bblock, 0, stream, B);
+      else hipLaunchKernelGGL(icamd_pad_etc1_border_kernel, bgrid, bblock, 0, stream, B);
     }
   } else return hipErrorInvalidValue;
   return hipGetLastError();
@@ -221,10 +230,12 @@ hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stre
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_downsample_dxt1_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_downsample_dxt5_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_ETC1) {
-    if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_downsample_etc1_split_h_kernel, grid, block, 0, stream, P);
-    else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_downsample_etc1_split_v_kernel, grid, block, 0, stream, P);
-    else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_downsample_etc1_heuristic_kernel, grid, block, 0, stream, P);
-    else hipLaunchKernelGGL(icamd_downsample_etc1_kernel, grid, block, 0, stream, P);
+    const uint32_t lanes = (uint32_t)blockop_lanes(ICAMD_ETC1, P.etc_strategy == 3u ? 3 : 2, 0);
+    const dim3 egrid((P.total_out + lanes - 1) / lanes), eblock(lanes);
+    if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_downsample_etc1_split_h_kernel, egrid, eblock, 0, stream, P);
+    else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_downsample_etc1_split_v_kernel, egrid, eblock, 0, stream, P);
+    else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_downsample_etc1_heuristic_kernel, egrid, eblock, 0, stream, P);
+    else hipLaunchKernelGGL(icamd_downsample_etc1_kernel, egrid, eblock, 0, stream, P);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
