@@ -157,4 +157,36 @@ for it in range(12 * n_seeds):
             bad += 1
             print("MISMATCH transcode of arbitrary words", h, w, kind)
 print("arbitrary block words through the palette-plane kernels: %d checks, %d mismatches in total, %.1f s" % (words, bad, time.time() - t0))
+
+# r05: the PVRTC one-pass kernel (textures of 512^2 and more: the soak above never reaches it), forced with a random strip height,
+# random batch and content, against the oracle; and the PVRTC 4 bpp extension against the oracle's restatement
+g = np.random.Generator(np.random.PCG64(0x0E9A55))
+one = 0
+try:
+    for it in range(max(4, n_seeds // 2)):
+        n = int(g.choice([512, 512, 1024, 1024, 2048]))
+        cnt = int(g.integers(1, 4))
+        imgs = np.stack([T.soak_image(g, n, n, 4) for _ in range(cnt)])
+        sb = int(g.integers(2, 7))
+        pkg.pvrtc_tune(2, sb)
+        out = pkg.encode_device(T.PVRTC2, torch.from_numpy(imgs).cuda(), n, n, 4, n_images=cnt)
+        torch.cuda.synchronize()
+        for i in range(cnt):
+            one += 1
+            if out[i].cpu().numpy().tobytes() != T.oracle_encode(T.PVRTC2, imgs[i], n, n, 4, threads=16):
+                bad += 1
+                print("MISMATCH pvrtc one-pass", n, cnt, sb, i)
+finally:
+    pkg.pvrtc_tune(0, -1)
+four = 0
+for it in range(8 * n_seeds):
+    n = 1 << int(g.integers(3, 10))
+    img = T.soak_image(g, n, n, 4)
+    out = pkg.encode_device(T.PVRTC4, torch.from_numpy(np.ascontiguousarray(img)).cuda(), n, n, 4)
+    torch.cuda.synchronize()
+    four += 1
+    if out.cpu().numpy().tobytes() != T.oracle_encode(T.PVRTC4, img, n, n, 4):
+        bad += 1
+        print("MISMATCH pvrtc4 (extension)", n, it)
+print("pvrtc one-pass soak: %d textures; pvrtc4 (extension) soak: %d textures; %d mismatches in total, %.1f s" % (one, four, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
