@@ -1012,6 +1012,159 @@ ICAMD_DEV uint32_t pvrtc4_block_data(const uint32_t px[16], const PvrtcColors nb
   return data;
 }
 
+// One-pass form of the 4 bpp encoder (r05), the 2 bpp walk of pvrtc_onepass_strip with 4-pixel rows: one lane = one 4-pixel
+// block column of a strip of K blocks.  The vertical structure is the 2 bpp one (blocks are 4 rows tall in both formats: rows
+// 2, 3 of block s-1 and rows 0, 1 of block s interpolate between colour rows s-1 and s with weights 0, 1, 2, 3), so a tick
+// again hands over pixel row m for the morph and row m - 5 for the modulation.  What falls away: the mode decision and its
+// neighbour terms (every pixel's value is stored), hence no deferred finish and no column exchange -- block s-1 is complete
+// after its row 3 in segment s.
+//   tick(m, mp[4], ep[4]); lookup10 as in pvrtc_keys_finish (indices 0..15); exchange(s, own, left, right): colours only;
+//   store(j, data, own).
+template <int Q>
+ICAMD_DEV void pvrtc4_keys_row(PvrtcMorphKeys &k, const uint32_t px[4]) {
+  ICAMD_UNROLL
+  for (int x = 0; x < 4; x += 2) {
+    uint32_t kl[2];
+    ICAMD_UNROLL
+    for (int q = 0; q < 2; ++q) {
+      const int p = 4 * Q + x + q;
+      const uint32_t c = px[x + q], i = (uint32_t)(p & 3);
+      const uint32_t idx4 = (uint32_t)(p & ~3) * 0x01010101u + 0x03020100u;
+      const uint32_t up = (uint32_t)(15 - 2 * p) * 0x00010001u;
+      kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
+      const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16), k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
+      k.min_rb = pk_min_u16(k.min_rb, k_rb);
+      k.min_ga = pk_min_u16(k.min_ga, k_ga);
+      k.max_rb = pk_max_u16(k.max_rb, k_rb + up);
+      k.max_ga = pk_max_u16(k.max_ga, k_ga + up);
+    }
+    const int p = 4 * Q + x;
+    k.min_l = umin3(k.min_l, kl[0], kl[1]);
+    k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(15 - 2 * p), kl[1] + (uint32_t)(15 - 2 * (p + 1)));
+  }
+  k.min_l = opaque(k.min_l); k.max_l = opaque(k.max_l);
+  k.min_rb = opaque(k.min_rb); k.max_rb = opaque(k.max_rb);
+  k.min_ga = opaque(k.min_ga); k.max_ga = opaque(k.max_ga);
+  ICAMD_SCHED_FENCE();
+}
+template <typename Lookup10>
+ICAMD_DEV void pvrtc4_keys_finish(const PvrtcMorphKeys &k, uint32_t image0, Lookup10 &lookup10, uint32_t &col_a, uint32_t &col_b) {
+  const uint32_t kmin[5] = { k.min_l, k.min_rb & 0xffffu, k.min_ga & 0xffffu, k.min_rb >> 16, k.min_ga >> 16 };
+  const uint32_t kmax[5] = { k.max_l, k.max_rb & 0xffffu, k.max_ga & 0xffffu, k.max_rb >> 16, k.max_ga >> 16 };
+  uint32_t idx[10], v[10];
+  ICAMD_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    idx[2 * i] = kmin[i] & 15u;
+    idx[2 * i + 1] = 15u - (kmax[i] & 15u);
+  }
+  lookup10(idx, v);
+  uint32_t best_diff = 0, best_lo = 0, best_hi = 0;
+  ICAMD_UNROLL
+  for (int i = 0; i < 5; ++i) {
+    const uint32_t lo = v[2 * i];
+    const uint32_t hi = (kmax[i] >> 8) == 0u ? image0 : v[2 * i + 1];
+    const uint32_t d = sad_u8(lo, hi, 0u);
+    const bool better = (i == 0) || d > best_diff;
+    best_lo = better ? lo : best_lo;
+    best_hi = better ? hi : best_hi;
+    best_diff = better ? d : best_diff;
+  }
+  const bool swap = udot4(best_hi, 0x01010101u, 0u) < udot4(best_lo, 0x01010101u, 0u);
+  col_a = swap ? best_hi : best_lo;
+  col_b = swap ? best_lo : best_hi;
+}
+// the four values of one pixel row as the row's 8 data bits (pixel x at bits 2 x)
+ICAMD_DEV uint32_t pvrtc4_row_bits(const uint32_t P0[4], const uint32_t D0[4], const uint32_t P1[4], const uint32_t D1[4],
+                                   const uint32_t px[4]) {
+  uint32_t acc = 0;
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t *Pb = h ? P1 : P0, *D = h ? D1 : D0;
+    uint32_t P[4] = { Pb[0], Pb[1], Pb[2], Pb[3] };
+    acc = opaque(accumulate_mod(px[2 * h], P, 1u << (16 * h), acc));
+    ICAMD_SCHED_FENCE();
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) P[v] += D[v];
+    acc = opaque(accumulate_mod(px[2 * h + 1], P, 1u << (16 * h + 8), acc));
+    ICAMD_SCHED_FENCE();
+  }
+  return udot4(acc, 0x40100401u, 0u);
+}
+template <typename Tick, typename Lookup10, typename Exchange, typename BlockStore>
+ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tick, Lookup10 &lookup10, Exchange &exchange,
+                                    BlockStore &store) {
+  const int K = (int)k_blocks;
+  PvrtcMorphKeys keys;
+  pvrtc_keys_reset(keys);
+  uint32_t mp[4], ep[4];
+  uint32_t A[3][4];
+  ICAMD_UNROLL
+  for (int c = 0; c < 3; ++c)
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) A[c][v] = 0u;
+  uint32_t data = 0u;
+  PvrtcColors own_acc = { 0u, 0u };
+  tick(-4, mp, ep); pvrtc4_keys_row<0>(keys, mp);
+  tick(-3, mp, ep); pvrtc4_keys_row<1>(keys, mp);
+  tick(-2, mp, ep); pvrtc4_keys_row<2>(keys, mp);
+  PvrtcColors cc[3] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+  ICAMD_NOUNROLL
+  for (int s = -1;; ++s) {
+    {
+      tick(4 * s + 3, mp, ep);
+      pvrtc4_keys_row<3>(keys, mp);
+      uint32_t a, c;
+      pvrtc4_keys_finish(keys, image0, lookup10, a, c);
+      cc[1].a = channel_reduce(a, false);
+      cc[1].b = channel_reduce(c, true);
+      pvrtc_keys_reset(keys);
+    }
+    exchange(s, cc[1], cc[0], cc[2]);
+    // colour rows (s-1, s): V = 16 A + w * 4 (B - A) for weight w = 0..3; from it the walks' bases and their steps per pixel row:
+    //   x = 0, 1: D = 4 (V[1] - V[0]), P = 8 (V[0] + V[1]);   x = 2, 3: D = 4 (V[2] - V[1]), P = 16 V[1]
+    uint32_t P0[4], D0[4], P1[4], D1[4], dP0[4], dD0[4], dP1[4], dD1[4];
+    ICAMD_UNROLL
+    for (int v = 0; v < 4; ++v) {
+      uint32_t Vc[3], dVc[3];
+      ICAMD_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
+        Vc[c] = A[c][v] << 4;
+        dVc[c] = (b - A[c][v]) << 2;
+        A[c][v] = b;
+      }
+      D0[v] = (Vc[1] - Vc[0]) << 2;   dD0[v] = (dVc[1] - dVc[0]) << 2;
+      P0[v] = (Vc[0] + Vc[1]) << 3;   dP0[v] = (dVc[0] + dVc[1]) << 3;
+      D1[v] = (Vc[2] - Vc[1]) << 2;   dD1[v] = (dVc[2] - dVc[1]) << 2;
+      P1[v] = Vc[1] << 4;             dP1[v] = dVc[1] << 4;
+    }
+#define ICAMD_ROW4_STEP()                                                                            \
+  ICAMD_UNROLL                                                                                       \
+  for (int v = 0; v < 4; ++v) { P0[v] += dP0[v]; D0[v] += dD0[v]; P1[v] += dP1[v]; D1[v] += dD1[v]; }
+    if (s >= 1) data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 16;  // row 2 of block s-1, weight 0
+    ICAMD_ROW4_STEP()
+    tick(4 * s + 4, mp, ep);
+    pvrtc4_keys_row<0>(keys, mp);
+    if (s >= 1) {  // row 3 of block s-1, weight 1: the block is complete
+      data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 24;
+      store((uint32_t)(s - 1), data, own_acc);
+    }
+    if (s == K) break;
+    ICAMD_ROW4_STEP()
+    tick(4 * s + 5, mp, ep);
+    pvrtc4_keys_row<1>(keys, mp);
+    if (s >= 0) {  // row 0 of block s, weight 2
+      own_acc = cc[1];
+      data = pvrtc4_row_bits(P0, D0, P1, D1, ep);
+    }
+    ICAMD_ROW4_STEP()
+    tick(4 * s + 6, mp, ep);
+    pvrtc4_keys_row<2>(keys, mp);
+    if (s >= 0) data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 8;  // row 1 of block s, weight 3
+#undef ICAMD_ROW4_STEP
+  }
+}
+
 // FromZOrder inverse (pvrtc.cc:80-86): x occupies the odd bits, y the even bits of the block index.
 ICAMD_DEV uint32_t spread_bits16(uint32_t v) {
   v = (v | v << 8) & 0x00ff00ffu;
@@ -1052,6 +1205,39 @@ static inline int emul_pvrtc4(const uint8_t *src, uint32_t n, uint8_t *out) {
       o[0] = pvrtc4_block_data(px, nb);
       o[1] = pvrtc_pack_colors(nb[1][1].a, nb[1][1].b, true);  // bit 0 clear: standard modulation
     }
+  // the one-pass walker (what icamd_pvrtc4_onepass_kernel runs) must reproduce every block for several strip heights
+  int ok = 1;
+  for (uint32_t k_blocks = 1; k_blocks <= 8 && k_blocks <= lw; k_blocks *= 2)
+    for (uint32_t by0 = 0; by0 < lw; by0 += k_blocks)
+      for (uint32_t bx = 0; bx < lw; ++bx) {
+        int last_m = -100;
+        auto tick = [&](int m, uint32_t *mp, uint32_t *ep) {
+          last_m = m;
+          const uint32_t ym = (by0 * 4 + (uint32_t)m) & (n - 1), ye = (by0 * 4 + (uint32_t)(m - 5)) & (n - 1);
+          for (int x = 0; x < 4; ++x) {
+            mp[x] = img[(size_t)ym * n + bx * 4 + x];
+            ep[x] = img[(size_t)ye * n + bx * 4 + x];
+          }
+        };
+        auto lookup10 = [&](const uint32_t idx[10], uint32_t v[10]) {
+          const uint32_t y0 = (by0 * 4 + (uint32_t)(last_m - 3)) & (n - 1);
+          for (int i = 0; i < 10; ++i) v[i] = img[(size_t)(y0 + idx[i] / 4) * n + bx * 4 + idx[i] % 4];
+        };
+        auto exchange = [&](int s, const PvrtcColors &own, PvrtcColors &left, PvrtcColors &right) {
+          const size_t row = (size_t)((by0 + lw + (uint32_t)s) % lw) * lw;
+          if (own.a != col[row + bx].a || own.b != col[row + bx].b) ok = 0;
+          left = col[row + (bx + lw - 1) % lw];
+          right = col[row + (bx + 1) % lw];
+        };
+        uint32_t stored = 0;
+        auto store = [&](uint32_t j, uint32_t data, const PvrtcColors &own) {
+          const uint32_t *o = reinterpret_cast<const uint32_t *>(out) + 2 * (size_t)(spread_bits16_host(bx) << 1 | spread_bits16_host(by0 + j));
+          if (o[0] != data || o[1] != pvrtc_pack_colors(own.a, own.b, true)) ok = 0;
+          stored |= 1u << j;
+        };
+        pvrtc4_onepass_strip(k_blocks, img[0], tick, lookup10, exchange, store);
+        if (!ok || stored != (1u << k_blocks) - 1u) { delete[] col; return 0; }
+      }
   delete[] col;
   return 1;
 }

@@ -1002,9 +1002,161 @@ extern "C" __global__ void __launch_bounds__(kEncodeLanes) icamd_pvrtc4_encode_k
   store_stream8(dst, data, pvrtc_pack_colors(nb[1][1].a, nb[1][1].b, true));  // bit 0 clear: standard modulation
 }
 
+// One-pass form (r05), the 4 bpp twin of icamd_pvrtc2_onepass_kernel: a workgroup is one whole block row of the texture wide
+// (size / 4 lanes: 64 ... 1 024 = textures of 256^2 ... 4096^2), one lane = one 4-pixel block column of a strip
+// (pvrtc4_onepass_strip).  A row slot of the per-wave ring is 64 lanes x 16 bytes = 1 KiB (one DMA instruction per row), eight
+// of them plus a 1 KiB tile of finished blocks (2 block rows, 32-byte runs) = 9 KiB per wave: sixteen waves per CU, four per
+// SIMD, which a 1 024-lane workgroup needs anyway (and which caps the walk at 128 VGPRs).
+constexpr uint32_t kOnePass4WaveDwords = kOnePassRing * 256u + 256u;  // ring + tile: 9 216 bytes
+constexpr uint32_t kOnePass4XchDwords = 4;                            // per wave and parity: lo.a lo.b hi.a hi.b
+struct Pvrtc4OnePass {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint64_t src_image_stride, dst_image_stride;
+  uint32_t log2_n, log2_strip, stage_stores;
+};
+extern "C" __global__ void __launch_bounds__(1024) icamd_pvrtc4_onepass_kernel(Pvrtc4OnePass L) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = 1u << L.log2_n, sb = L.log2_strip, K = 1u << sb;
+  const uint32_t log2_spi = L.log2_n - 2u - sb;  // strips per image = (size / 4) >> sb
+  const uint32_t image = blockIdx.x >> log2_spi, by0 = (blockIdx.x & ((1u << log2_spi) - 1u)) << sb;
+  const uint32_t bx = threadIdx.x, lane = threadIdx.x & 63u;
+  const uint32_t W = blockDim.x >> 6;
+  const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+  uint2 *dst = reinterpret_cast<uint2 *>(L.dst + (size_t)image * L.dst_image_stride);
+  const uint32_t image0 = opaque(img[0]);
+  lds_u32 *ring = (lds_u32 *)(lds_dyn + wave_s * kOnePass4WaveDwords);
+  const uint32_t ring_lane_byte = (uint32_t)(uintptr_t)ring + lane * 16u;
+  const uint32_t tile_byte = (uint32_t)(uintptr_t)ring + kOnePassRing * 1024u;
+  const uint32_t xch_byte = (uint32_t)(uintptr_t)(lds_u32 *)(lds_dyn + W * kOnePass4WaveDwords);
+  const int last_row = (int)(4u * K + 3u);
+  auto dma_row = [&](int m) {
+    const uint32_t y = (by0 * 4u + (uint32_t)(m < last_row ? m : last_row)) & (n - 1u);
+    __builtin_amdgcn_global_load_lds(img + ((y << L.log2_n) + bx * 4u), ring + ((uint32_t)m & (kOnePassRing - 1u)) * 256u, 16, 0, 0);
+  };
+  dma_row(-4); dma_row(-3); dma_row(-2);
+  int cur_m = -4;
+  auto tick = [&](int m, uint32_t *mp, uint32_t *ep) {
+    cur_m = m;
+    // rows m + 1 and m + 2 (one DMA instruction each) may still be in flight
+    const uint32_t addr_m = ring_lane_byte + ((uint32_t)m & 7u) * 1024u, addr_e = ring_lane_byte + ((uint32_t)(m + 3) & 7u) * 1024u;
+    uint4 m0, e0;
+    asm volatile("s_waitcnt vmcnt(2)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(m0), "=&v"(e0) : "v"(addr_m), "v"(addr_e) : "memory");
+    mp[0] = m0.x; mp[1] = m0.y; mp[2] = m0.z; mp[3] = m0.w;
+    ep[0] = e0.x; ep[1] = e0.y; ep[2] = e0.z; ep[3] = e0.w;
+    dma_row(m + 3);
+  };
+  auto lookup10 = [&](const uint32_t idx[10], uint32_t v[10]) {
+    const uint32_t base = ring_lane_byte + ((uint32_t)(cur_m - 3) & 7u) * 1024u;
+    uint32_t a[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) a[i] = base + ((idx[i] & 12u) << 8) + ((idx[i] & 3u) << 2);
+    asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %12\n\tds_read_b32 %3, %13\n\t"
+                 "ds_read_b32 %4, %14\n\tds_read_b32 %5, %15\n\tds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\t"
+                 "ds_read_b32 %8, %18\n\tds_read_b32 %9, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9])
+                 : "memory");
+  };
+  const uint32_t left_wave = (wave_s == 0u ? W : wave_s) - 1u, right_wave = wave_s + 1u == W ? 0u : wave_s + 1u;
+  auto exchange = [&](int s, const PvrtcColors &own, PvrtcColors &left, PvrtcColors &right) {
+    const uint32_t x = xch_byte + ((uint32_t)s & 1u) * (W * kOnePass4XchDwords * 4u);
+    const uint32_t mine = x + wave_s * (kOnePass4XchDwords * 4u);
+    const uint2 c = make_uint2(own.a, own.b);
+    if (lane == 0u) asm volatile("ds_write_b64 %0, %1" :: "v"(mine), "v"(c) : "memory");
+    if (lane == 63u) asm volatile("ds_write_b64 %0, %1 offset:8" :: "v"(mine), "v"(c) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint2 l, r;
+    const uint32_t al = x + left_wave * (kOnePass4XchDwords * 4u), ar = x + right_wave * (kOnePass4XchDwords * 4u);
+    asm volatile("ds_read_b64 %0, %2 offset:8\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(r) : "v"(al), "v"(ar) : "memory");
+    const uint32_t la = dpp_from_lower_lane(own.a), lb = dpp_from_lower_lane(own.b);
+    const uint32_t ra = dpp_from_upper_lane(own.a), rb = dpp_from_upper_lane(own.b);
+    left.a = lane == 0u ? l.x : la;   left.b = lane == 0u ? l.y : lb;
+    right.a = lane == 63u ? r.x : ra; right.b = lane == 63u ? r.y : rb;
+  };
+  // tile: chunk = lane / 2 (two block columns x two block rows = four consecutive Z slots = 32 bytes)
+  const uint32_t tile_lane_byte = tile_byte + ((lane >> 1) * 4u + ((lane & 1u) << 1)) * 8u;
+  const uint32_t zx = spread_bits16(bx) << 1;
+  const uint32_t flush_lds = tile_byte + lane * 16u;                                        // pair `lane`: chunk lane / 2, slots 2 (lane & 1) ..
+  const uint32_t flush_zx = (spread_bits16(wave_s * 64u + (lane & ~1u)) << 1) + ((lane & 1u) << 1);
+  auto store = [&](uint32_t j, uint32_t data, const PvrtcColors &own) {
+    const uint2 v = make_uint2(data, pvrtc_pack_colors(own.a, own.b, true));  // bit 0 clear: standard modulation
+    if (!L.stage_stores) {
+      asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + (zx | spread_bits16(by0 + j))), "v"(v) : "memory");
+      return;
+    }
+    asm volatile("ds_write_b64 %0, %1" :: "v"(tile_lane_byte + (j & 1u) * 8u), "v"(v) : "memory");
+    if (!(j & 1u)) return;
+    icamd_u32x4 q;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(q) : "v"(flush_lds) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst + (flush_zx | spread_bits16(by0 + j - 1u))), "v"(q) : "memory");
+  };
+  pvrtc4_onepass_strip(K, image0, tick, lookup10, exchange, store);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+namespace {
+// Strip height of the 4 bpp one-pass kernel, or -1 where the pair is the better choice.  Measured (r05, profiles/
+// r05_ab_pvrtc4_onepass.log): a strip workgroup takes 11 + 5.8 K us on a full CU whatever its width -- the 2 bpp kernel's
+// figure: the same pixels per CU and block row --, a CU holds 16 / waves-per-workgroup of them; the pair takes 10 us + 1.87 us per
+// million pixels.  Below ~8 Mpixel per launch neither fills the chip and the pair's two short kernels are as fast or faster
+// (1 x 2048^2: 15 vs 21 us), so it keeps those.
+int onepass4_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always) {
+  const uint32_t log2_bw = log2_size - 2u;  // blocks per row = lanes per workgroup
+  if (log2_bw < 6u || log2_bw > 10u) return -1;
+  if (forced >= 0) return forced < 1 ? 1 : (forced > (int)log2_bw ? (int)log2_bw : forced);
+  const uint64_t pixels = n_images << (2u * log2_size);
+  if (!always && pixels < (8ull << 20)) return -1;
+  const uint64_t slots = 256ull * (16u >> (log2_bw - 6u));
+  int best = -1;
+  double best_us = 0.0;
+  for (int sb = 2; sb <= 6 && sb <= (int)log2_bw; ++sb) {
+    const uint64_t wgs = n_images << (log2_bw - (uint32_t)sb);
+    const double us = (double)((wgs + slots - 1) / slots) * (11.0 + 5.8 * (double)(1u << sb));
+    if (best < 0 || us <= best_us) { best_us = us; best = sb; }
+  }
+  const double pair_us = 10.0 + 1.87e-6 * (double)pixels;
+  return always || best_us < 0.97 * pair_us ? best : -1;
+}
+hipError_t launch_pvrtc4_onepass(const PvrtcParams &P, int sb, hipStream_t stream) {
+  const uint32_t lanes = P.size / 4u, waves = lanes >> 6;
+  const size_t lds_bytes = (size_t)waves * (kOnePass4WaveDwords + 2u * kOnePass4XchDwords) * 4u;
+  static std::atomic<uint64_t> allowed{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 64 && !((allowed.load() >> dev) & 1u)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(icamd_pvrtc4_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(16u * (kOnePass4WaveDwords + 2u * kOnePass4XchDwords) * 4u));
+    if (e != hipSuccess) return e;
+    allowed.fetch_or(1ull << dev);
+  }
+  Pvrtc4OnePass L;
+  L.src = P.src;
+  L.dst = P.dst;
+  L.src_image_stride = P.src_image_stride;
+  L.dst_image_stride = P.dst_image_stride;
+  L.log2_n = P.log2_size;
+  L.log2_strip = (uint32_t)sb;
+  L.stage_stores = (reinterpret_cast<uintptr_t>(P.dst) % 16u == 0 && (P.n_images == 1 || P.dst_image_stride % 16u == 0)) ? 1u : 0u;
+  const uint32_t strips_per_image = lanes >> sb;
+  hipLaunchKernelGGL(icamd_pvrtc4_onepass_kernel, dim3((uint32_t)(P.n_images * (uint64_t)strips_per_image)), dim3(lanes), lds_bytes, stream, L);
+  return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_pvrtc4(const PvrtcParams &P, hipStream_t stream) {
   if (P.n_images == 0) return hipSuccess;
   if (P.region_blocks != 0) return hipErrorInvalidValue;
+  read_path_env();
+  if (g_path_mode.load() != 1 && (uint64_t)(P.size / 4) * (P.size / 4) * P.n_images < (1ull << 31)) {
+    const bool force = g_path_mode.load() == 2;
+    const int sb = onepass4_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force);
+    if (sb >= 0) return launch_pvrtc4_onepass(P, sb, stream);
+  }
   const uint64_t bpi = (uint64_t)(P.size / 4) * (P.size / 4);
   const uint64_t group = pvrtc_group(P.size, P.n_images);
   if (bpi * group >= (1ull << 31)) return hipErrorInvalidValue;

@@ -361,7 +361,7 @@ def test_pvrtc_onepass_kernel_every_strip_height_matches_oracle(pkg, pvrtc_auto)
             assert not host[off + (cnt - 1) * dst_stride + per:].any() and not host[:off].any()
 
 
-def test_pvrtc4_extension_matches_the_oracles_restatement_and_decodes(pkg):
+def test_pvrtc4_extension_matches_the_oracles_restatement_and_decodes(pkg, pvrtc_auto):
     """PVRTC1 4 bpp (EXTENSION, parity unpinned: BASELINE config 5 names it, the reference has none): the device kernels
     against oracle/ic_oracle.c's restatement of the same rules (8^2 ... 4096^2, all contents, the image-pixel-0 rule, batches
     with padded strides), and the decoded result against the source (the only outside check there is)."""
@@ -376,6 +376,20 @@ def test_pvrtc4_extension_matches_the_oracles_restatement_and_decodes(pkg):
     img[8:, :, 1] = 200
     img[:, 16:, 3] = 255
     assert _host(pkg.encode_device(T.PVRTC4, _dev(img), 32, 32, 4)) == T.oracle_encode(T.PVRTC4, img, 32, 32, 4)
+    # both forms on every eligible size: the morph + encode pair and the one-pass kernel (icamd_pvrtc4_onepass_kernel: a
+    # workgroup = one block row of the texture, 64 ... 1 024 lanes) at every strip height
+    for n in (256, 512, 2048):
+        imgs = np.stack([T.GENERATORS[gen](n, n, 4, index=n + 2) for gen in ("noise", "smooth", "flat", "mixed")])
+        want = [T.oracle_encode(T.PVRTC4, im, n, n, 4) for im in imgs]
+        d = _dev(imgs)
+        for mode, strips in ((1, (-1,)), (2, (1, 2, 3, 4, 5, 6, 7))):
+            for sb in strips:
+                assert pkg.pvrtc_tune(mode, sb)
+                out = pkg.encode_device(T.PVRTC4, d, n, n, 4, n_images=4)
+                torch.cuda.synchronize()
+                for i in range(4):
+                    assert out[i].cpu().numpy().tobytes() == want[i], (n, mode, sb, i)
+    assert pkg.pvrtc_tune(2, 4)  # (the rest of this test: the one-pass form where eligible, then automatic)
     n, cnt = 512, 5
     imgs = np.stack([T.s_mixed(n, n, 4, index=70 + i) for i in range(cnt)])
     src = torch.zeros((cnt, n * n * 4 + 64), dtype=torch.uint8, device="cuda")
@@ -388,11 +402,22 @@ def test_pvrtc4_extension_matches_the_oracles_restatement_and_decodes(pkg):
     for i in range(cnt):
         assert out[i, :per].cpu().numpy().tobytes() == T.oracle_encode(T.PVRTC4, imgs[i], n, n, 4), i
         assert not out[i, per:].any()
+    # an 8-mod-16 destination: no staged 16-byte stores
+    buf = torch.zeros(cnt * per + 64, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().icamd_encode_device(T.PVRTC4, 2, 4, 0, n, n, n, n, n * 4, cnt, n * n * 4 + 64, per, src.data_ptr(),
+                                         buf.data_ptr() + 8, None) == pkg.OK
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    for i in range(cnt):
+        assert host[8 + i * per: 8 + (i + 1) * per].tobytes() == T.oracle_encode(T.PVRTC4, imgs[i], n, n, 4), i
+    assert pkg.pvrtc_tune(0, -1)
     n = 4096
     img = T.s_smooth(n, n, 4, index=21)
     img[:1024, :1024] = T.s_noise(1024, 1024, 4, index=21)
-    got = _host(pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4))
+    got = _host(pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4))  # (16 Mpixel: the automatic choice is the one-pass kernel)
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(T.oracle_encode(T.PVRTC4, img, n, n, 4)).hexdigest()
+    assert pkg.pvrtc_tune(1, -1)
+    assert _host(pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4)) == got
     dec = T.oracle_decode(T.PVRTC4, got, n, n).reshape(n, n, 4).astype(np.float64)
     mse = float(((dec[1024:] - img[1024:].astype(np.float64)) ** 2).mean())
     assert 10 * np.log10(255.0 * 255.0 / mse) > 18.0  # the smooth part (ramps + 5-bit noise + random alpha)

@@ -185,3 +185,28 @@ def test_pvrtc_encode_kernel_colour_rows_are_not_used_before_their_wait(tmp_path
             groups += 1
         i = j
     assert groups >= 2, groups  # colour rows -1 and 0 in front of the strip loop
+
+
+def test_pvrtc4_onepass_kernel_ring_protocol_as_compiled(tmp_path):
+    """The 4 bpp one-pass kernel (extension) uses the 2 bpp kernel's ring protocol with ONE DMA instruction per row: a tick
+    issues one row and waits with `s_waitcnt vmcnt(2)`.  A 1 024-lane workgroup caps it at 128 VGPRs; no scratch."""
+    text = _asm("pvrtc_kernels.hip", tmp_path)
+    meta = _kernel_meta(text, "icamd_pvrtc4_onepass_kernel")
+    assert meta["scratch"] == 0 and meta["vgprs"] <= 128 and meta["lds"] == 0, meta
+    body = _body(text, "icamd_pvrtc4_onepass_kernel")
+    loop = next(i for i, l in enumerate(body) if "Inner Loop Header" in l)
+    back = max(i for i, l in enumerate(body) if re.match(r"\s+s_cbranch_\w+\s+\.LBB\d+_\d+", l))
+    in_asm, stray = False, []
+    for l in body:
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif re.match(r"\s+(ds_|global_|buffer_|flat_|scratch_)", l) and not in_asm and "global_load_lds" not in l:
+            stray.append(l.strip())
+    assert not stray, stray[:4]
+    assert sum("global_load_lds_dwordx4" in l for l in body[:loop]) == 3 + 3
+    walk = body[loop:back + 1]
+    waits = [re.sub(r"\s+", " ", l.strip()) for l in walk if "s_waitcnt" in l and "vmcnt" in l]
+    assert sum("global_load_lds_dwordx4" in l for l in walk) == 4 and waits == ["s_waitcnt vmcnt(2)"] * 4, waits
+    assert sum(bool(re.match(r"\s+s_barrier", l)) for l in walk) == 1
