@@ -1188,7 +1188,7 @@ size_t pvrtc4_workspace_bytes(uint32_t size, uint32_t n_images) {
   if (n_images == 0) return 0;
   return (size_t)((uint64_t)(size / 4) * (size / 4) * pvrtc_group(size, n_images) * sizeof(uint2));
 }
-const char *pvrtc4_kernel_name() { return "icamd_pvrtc4_encode_kernel"; }
+const char *pvrtc4_kernel_name() { return "icamd_pvrtc4_onepass_kernel"; }
 
 size_t pvrtc2_workspace_bytes(uint32_t size, uint32_t n_images) {
   if (n_images == 0) return 0;
