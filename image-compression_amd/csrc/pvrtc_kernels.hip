@@ -820,11 +820,11 @@ hipError_t launch_pvrtc2_onepass(const PvrtcParams &P, int sb, hipStream_t strea
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev < 64 && !((allowed.load() >> dev) & 1u)) {
+  if (dev < 0 || dev >= 64 || !((allowed.load() >> dev) & 1u)) {  // (ordinals past 63: every time)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(icamd_pvrtc2_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(8u * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u));
     if (e != hipSuccess) return e;
-    allowed.fetch_or(1ull << dev);
+    if (dev >= 0 && dev < 64) allowed.fetch_or(1ull << dev);
   }
   PvrtcLaunch L;
   L.src = P.src;
@@ -1128,11 +1128,11 @@ hipError_t launch_pvrtc4_onepass(const PvrtcParams &P, int sb, hipStream_t strea
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (dev < 64 && !((allowed.load() >> dev) & 1u)) {
+  if (dev < 0 || dev >= 64 || !((allowed.load() >> dev) & 1u)) {  // (ordinals past 63: every time)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(icamd_pvrtc4_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(16u * (kOnePass4WaveDwords + 2u * kOnePass4XchDwords) * 4u));
     if (e != hipSuccess) return e;
-    allowed.fetch_or(1ull << dev);
+    if (dev >= 0 && dev < 64) allowed.fetch_or(1ull << dev);
   }
   Pvrtc4OnePass L;
   L.src = P.src;

@@ -5,10 +5,10 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/bench_all.jsonl; : > $O
 for wl in dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8; do
   for c in noise smooth flat; do
-    python bench.py --steps 40 --warmup 5 --workload $wl --content $c --no-cpu-baseline --no-host-api --no-sustained --no-single-image 2>/dev/null | tail -1 >> $O
+    python bench.py --steps 40 --warmup 5 --workload $wl --content $c --no-cpu-baseline --no-host-api --no-sustained --no-single-image --no-live-traffic 2>/dev/null | tail -1 >> $O
   done
 done
-for s in 0 1 3; do python bench.py --steps 40 --warmup 5 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline --no-host-api --no-sustained --no-single-image 2>/dev/null | tail -1 >> $O; done
+for s in 0 1 3; do python bench.py --steps 40 --warmup 5 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline --no-host-api --no-sustained --no-single-image --no-live-traffic 2>/dev/null | tail -1 >> $O; done
 # the BASELINE presets exactly as the driver runs them (all legs: sustained, single image, clock, cpu baseline, host API)
 for cfg in c2 c3 c4 c5 c5_4bpp; do python bench.py --config $cfg --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O; done
 python - <<'PY'

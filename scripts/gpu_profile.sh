@@ -15,7 +15,7 @@ rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 WLS=${@:-dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8}
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
-COMMON="--no-cpu-baseline --no-verify --no-host-api --no-sustained --no-single-image --no-extra-configs --no-slab"
+COMMON="--no-cpu-baseline --no-verify --no-host-api --no-sustained --no-single-image --no-extra-configs --no-slab --no-live-traffic"
 for wl in $WLS; do
   T="python bench.py --steps 100 --warmup 5 --precondition-seconds 0.5 --workload $wl $COMMON"
   B="python bench.py --steps 20 --warmup 3 --precondition-seconds 0 --workload $wl $COMMON"

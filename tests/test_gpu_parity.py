@@ -960,6 +960,14 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, (name, leg)
     assert d["configs"]["c4"]["textures_per_gpu_per_step"] == 1024 and d["configs"]["c4"]["etc_strategy"] == 2
     assert d["configs"]["c5"]["roofline"]["traffic"] and d["roofline"]["traffic"]
+    # r05: `traffic` is measured in the run itself (two rocprofv3 --pmc child passes per launch shape) and agrees with the
+    # committed profile of the same launch shape; algorithmic bytes <= traffic < 1.1 x algorithmic for the one-pass kernels
+    for name, roof, algo in [("c2", d["roofline"], 16 * 4096 * 4096 * 4.5), ("c5", d["configs"]["c5"]["roofline"], 16 * 4096 * 4096 * 4.25),
+                             ("c5_4bpp", d["configs"]["c5_4bpp"]["roofline"], 16 * 4096 * 4096 * 4.5)]:
+        assert roof["traffic_source"].startswith("measured in this run"), (name, roof["traffic_source"])
+        assert algo <= roof["traffic"] < 1.1 * algo, (name, roof["traffic"], algo)
+        if roof["traffic_committed_profile"]:
+            assert abs(roof["traffic"] / roof["traffic_committed_profile"] - 1) < 0.02, (name, roof)
     for name, leg in d["slab"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
         assert leg["distinct_images_rotated"] >= 5 and leg["distinct_source_MiB_per_rank"] >= 320, (name, leg)
