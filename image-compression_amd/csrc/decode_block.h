@@ -174,67 +174,91 @@ ICAMD_DEV void pvrtc_expand_colors(uint32_t colour_word, uint32_t out[4]) {
   out[0] = pair_rb(a); out[1] = pair_ga(a); out[2] = pair_rb(b); out[3] = pair_ga(b);
 }
 
+// v_pk_mad_u16 with ONE 16-bit lane of w feeding both products (the compiler folds the broadcast into op_sel):
+// lane k of the result = a.lane[k] * w.lane[L] + c.lane[k]  (mod 2^16)
+template <int L>
+ICAMD_DEV uint32_t pk_mad_u16_lane(uint32_t a, uint32_t w, uint32_t c) {
+#if defined(ICAMD_HOST_EMULATION)
+  const uint32_t ww = (w >> (16 * L)) & 0xffffu;
+  return pk_mad_u16(a, ww | ww << 16, c);
+#else
+  const icamd_dxt_us2 v = as_us2(w);
+  return from_us2(as_us2(a) * __builtin_shufflevector(v, v, L, L) + as_us2(c));
+#endif
+}
+
+// The eight weights one block STORES for its pixel row y (bits = the row's byte of the modulation word): out[h] byte
+// x & 3 of half h = x >> 2; 2BPP rows hold 0 at the pixels the block stores nothing for (odd checkerboard parity).
+//   1BPP: bit x -> 8 * bit.  nibble * 0x204081 puts bit i at 8 i (the sixteen partial products land on distinct bits:
+//         i + 7 k for i, k in 0..3).
+//   2BPP: sample j (2 bits) belongs to pixel 2 j + (y & 1); {0, 3, 5, 8}[s] = 3 s - (s >> 1); the two samples whose low
+//         bit is a sub-mode flag (bit positions 0 and 20, pvrtc.cc:474-487) keep only their high bit: (s >> 1) * 8.
+template <int Y>
+ICAMD_DEV void pvrtc_stored_row(uint32_t data, bool two, uint32_t out[2]) {
+  // (the nibble enters pre-multiplied by 8 so that both factors stay below 2^24: v_mul_u32_u24, not the quarter-rate full multiply)
+  const uint32_t n0 = (Y == 0 ? data << 3 : data >> (8 * Y - 3)) & 0x78u, n1 = (data >> (8 * Y + 1)) & 0x78u;
+  const uint32_t one0 = umad24(n0, 0x204081u, 0u) & 0x08080808u;
+  const uint32_t one1 = umad24(n1, 0x204081u, 0u) & 0x08080808u;
+  const uint32_t bits = bfe(data, 8 * Y, 8);
+  const uint32_t t = bits | bits << 12;
+  const uint32_t S = (t | t << 6) & 0x03030303u;                                     // byte j = s_j
+  uint32_t w4 = 3u * S - ((S >> 1) & 0x01010101u);                                   // byte j = {0, 3, 5, 8}[s_j]
+  if (Y == 0) w4 = (w4 & 0xffffff00u) | ((S & 0x00000002u) << 2);
+  if (Y == 2) w4 = (w4 & 0xff00ffffu) | ((S & 0x00020000u) << 2);
+  const uint32_t two0 = perm(0u, w4, (Y & 1) ? 0x010c000cu : 0x0c010c00u);
+  const uint32_t two1 = perm(0u, w4, (Y & 1) ? 0x030c020cu : 0x0c030c02u);
+  out[0] = two ? two0 : one0;
+  out[1] = two ? two1 : one1;
+}
+
 // C[r][c][v]: expanded colours of the 3 x 3 block neighbourhood.  mod / col are indexed like the neighbourhood
 // (3 * (dy + 1) + dx + 1) but only the block's own words (4) and its four orthogonal neighbours' (1, 3, 5, 7) are read.
-ICAMD_DEV void decode_pvrtc2_block_expanded(const uint32_t C[3][3][4], const uint32_t mod[9], const uint32_t col[9],
-                                            uint32_t px[32]) {
+// emit(y, row): the eight decoded pixels of pixel row y (R,G,B,A dwords), called as soon as the row is complete -- the
+// kernels store from there, so a block's eight stores leave spread over its arithmetic instead of in one burst at its end.
+template <typename Emit>
+ICAMD_DEV void decode_pvrtc2_block_rows(const uint32_t C[3][3][4], const uint32_t mod[9], const uint32_t col[9], Emit emit) {
   const uint32_t data = mod[4];
   const bool two = (col[4] & 1u) != 0u;
 
-  // ---- stored weights of the block's own pixels: W[y][h], byte x & 3 of W[y][x >> 2] (0 where nothing is stored)
-  uint32_t W[4][2];
-  ICAMD_UNROLL
-  for (int y = 0; y < 4; ++y) {
-    const uint32_t bits = (data >> (8 * y)) & 0xffu;
-    // 1BPP: bit x of the row -> 8 * bit in byte x
-    const uint32_t lo = bits & 0xfu, hi = bits >> 4;
-    const uint32_t one0 = ((lo | lo << 7 | lo << 14 | lo << 21) & 0x01010101u) << 3;
-    const uint32_t one1 = ((hi | hi << 7 | hi << 14 | hi << 21) & 0x01010101u) << 3;
-    // 2BPP: sample j (2 bits) of the row belongs to pixel x = 2 j + (y & 1)
-    const uint32_t S = (bits | bits << 6 | bits << 12 | bits << 18) & 0x03030303u;  // byte j = s_j
-    uint32_t w4 = 3u * S - ((S >> 1) & 0x01010101u);                                  // byte j = {0, 3, 5, 8}[s_j]
-    if (y == 0) w4 = (w4 & 0xffffff00u) | ((S & 0x00000002u) << 2);                   // bit position 0: (s >> 1) * 8
-    if (y == 2) w4 = (w4 & 0xff00ffffu) | ((S & 0x00020000u) << 2);                   // bit position 20
-    const uint32_t two0 = perm(0u, w4, (y & 1) ? 0x010c000cu : 0x0c010c00u);
-    const uint32_t two1 = perm(0u, w4, (y & 1) ? 0x030c020cu : 0x0c030c02u);
-    W[y][0] = two ? two0 : one0;
-    W[y][1] = two ? two1 : one1;
-  }
-  // ---- the 12 weights of neighbouring blocks that the block's unstored pixels look at (all of even parity there)
+  // ---- stored weights of the block's own pixels and of the rows above / below it (r05: whole rows, one routine)
+  uint32_t W[4][2], up[2], dn[2];
+  pvrtc_stored_row<0>(data, two, W[0]);
+  pvrtc_stored_row<1>(data, two, W[1]);
+  pvrtc_stored_row<2>(data, two, W[2]);
+  pvrtc_stored_row<3>(data, two, W[3]);
+  pvrtc_stored_row<3>(mod[1], (col[1] & 1u) != 0u, up);
+  pvrtc_stored_row<0>(mod[7], (col[7] & 1u) != 0u, dn);
+  // ---- the 4 weights of the left / right blocks that the block's unstored pixels look at (all of even parity there)
   const uint32_t l1 = pvrtc_stored_weight(mod[3], (col[3] & 1u) != 0u, 7u, 1u), l3 = pvrtc_stored_weight(mod[3], (col[3] & 1u) != 0u, 7u, 3u);
   const uint32_t r0 = pvrtc_stored_weight(mod[5], (col[5] & 1u) != 0u, 0u, 0u), r2 = pvrtc_stored_weight(mod[5], (col[5] & 1u) != 0u, 0u, 2u);
-  uint32_t up[2] = { 0u, 0u }, dn[2] = { 0u, 0u };
-  ICAMD_UNROLL
-  for (int x = 0; x < 8; ++x) {
-    if (x & 1) up[x >> 2] |= pvrtc_stored_weight(mod[1], (col[1] & 1u) != 0u, (uint32_t)x, 3u) << (8 * (x & 3));
-    else dn[x >> 2] |= pvrtc_stored_weight(mod[7], (col[7] & 1u) != 0u, (uint32_t)x, 0u) << (8 * (x & 3));
-  }
-  // ---- weights of all 32 pixels
-  const bool avg4 = (data & 1u) == 0u, vertical = (data & (1u << 20)) != 0u;
+  // ---- weights of all 32 pixels.  The three interpolation modes are one formula on packed bytes: with hs = l + r and
+  // vs = u + d, (hs + vs + 2) >> 2 is the four-neighbour average, and the two-neighbour ones are the same expression
+  // with hs or vs taken twice ((2 vs + 2) >> 2 == (vs + 1) >> 1); no carries between bytes (4 * 8 + 2 < 256).
+  const uint32_t only_v = ((data & 1u) != 0u && (data & (1u << 20)) != 0u) ? 0xffffffffu : 0u;
+  const uint32_t only_h = ((data & 1u) != 0u && (data & (1u << 20)) == 0u) ? 0xffffffffu : 0u;
   uint32_t Wf[4][2];
   ICAMD_UNROLL
   for (int y = 0; y < 4; ++y) {
-    const uint32_t lcol = y == 1 ? l1 : y == 3 ? l3 : 0u;            // left of pixel 0 (only odd rows look there)
-    const uint32_t rcol = y == 0 ? r0 : y == 2 ? r2 : 0u;            // right of pixel 7 (only even rows)
-    const uint32_t left[2] = { W[y][0] << 8 | lcol, alignbit(W[y][1], W[y][0], 24) };
-    const uint32_t right[2] = { alignbit(W[y][1], W[y][0], 8), W[y][1] >> 8 | rcol << 24 };
+    const uint32_t left[2] = { y == 1 ? (W[y][0] << 8 | l1) : y == 3 ? (W[y][0] << 8 | l3) : W[y][0] << 8, alignbit(W[y][1], W[y][0], 24) };
+    const uint32_t right[2] = { alignbit(W[y][1], W[y][0], 8), y == 0 ? (W[y][1] >> 8 | r0 << 24) : y == 2 ? (W[y][1] >> 8 | r2 << 24) : W[y][1] >> 8 };
     ICAMD_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t u = y > 0 ? W[y - 1][h] : up[h], d = y < 3 ? W[y + 1][h] : dn[h];
-      const uint32_t a4 = ((left[h] + right[h] + u + d + 0x02020202u) >> 2) & 0x0f0f0f0fu;
-      const uint32_t av = ((u + d + 0x01010101u) >> 1) & 0x0f0f0f0fu;
-      const uint32_t ah = ((left[h] + right[h] + 0x01010101u) >> 1) & 0x0f0f0f0fu;
-      const uint32_t interp = avg4 ? a4 : vertical ? av : ah;
+      const uint32_t hs = left[h] + right[h], vs = u + d;
+      const uint32_t first = (vs & only_v) | (hs & ~only_v), second = (hs & only_h) | (vs & ~only_h);
+      const uint32_t interp = ((first + second + 0x02020202u) >> 2) & 0x0f0f0f0fu;
       const uint32_t stored_at = (y & 1) ? 0xff00ff00u : 0x00ff00ffu;  // even checkerboard parity
       Wf[y][h] = two ? ((W[y][h] & stored_at) | (interp & ~stored_at)) : W[y][h];
     }
   }
-  // ---- colours
+  // ---- colours.  r05: the weights enter as 32 w and 256 - 32 w on 16-bit lanes, two pixels per register, the lane picked by
+  // the multiply itself (op_sel): (256 - 32 w) A + 32 w B = 32 ((8 - w) A + w B) <= 65 280 still fits a lane, and its HIGH
+  // byte is ((8 - w) A + w B) >> 3 -- one byte permute assembles the pixel, no shift.
   ICAMD_UNROLL
   for (int y = 0; y < 4; ++y) {
     const int r0b = y < 2 ? 0 : 1;                     // block rows (r0b, r0b + 1) bracket this pixel row
     const uint32_t yw = (uint32_t)((y + 2) & 3);
-    uint32_t V[3][4];
+    uint32_t V[3][4], row[8];
     ICAMD_UNROLL
     for (int c = 0; c < 3; ++c)
       ICAMD_UNROLL
@@ -248,20 +272,38 @@ ICAMD_DEV void decode_pvrtc2_block_expanded(const uint32_t C[3][3][4], const uin
         D[v] = vr - vl;
         P[v] = h == 0 ? (vl + vr) << 2 : vl << 3;     // xw = 4 / xw = 0
       }
+      uint32_t w32[2], iw32[2];
+      w32[0] = perm(0u, Wf[y][h], 0x0c010c00u) << 5;   // lanes: 32 w of pixels 0, 1
+      w32[1] = perm(0u, Wf[y][h], 0x0c030c02u) << 5;   //                       2, 3
+      iw32[0] = 0x01000100u - w32[0];
+      iw32[1] = 0x01000100u - w32[1];
       ICAMD_UNROLL
       for (int j = 0; j < 4; ++j) {
-        const uint32_t w2 = perm(0u, Wf[y][h], 0x0c000c00u + (uint32_t)j * 0x00010001u);  // {w, 0, w, 0} of byte j
-        const uint32_t iw2 = 0x00080008u - w2;
-        const uint32_t rb = pk_lshr16(pk_mad_u16(pk_lshr16(P[2], 8), w2, pk_mad_u16(pk_lshr16(P[0], 8), iw2, 0u)), 3);
-        const uint32_t ga = pk_lshr16(pk_mad_u16(pk_lshr16(P[3], 8), w2, pk_mad_u16(pk_lshr16(P[1], 8), iw2, 0u)), 3);
-        px[8 * y + 4 * h + j] = unpair(rb, ga);
+        const uint32_t a_rb = pk_lshr16(P[0], 8), a_ga = pk_lshr16(P[1], 8), b_rb = pk_lshr16(P[2], 8), b_ga = pk_lshr16(P[3], 8);
+        uint32_t rb, ga;
+        if (j & 1) {
+          rb = pk_mad_u16_lane<1>(b_rb, w32[j >> 1], pk_mad_u16_lane<1>(a_rb, iw32[j >> 1], 0u));
+          ga = pk_mad_u16_lane<1>(b_ga, w32[j >> 1], pk_mad_u16_lane<1>(a_ga, iw32[j >> 1], 0u));
+        } else {
+          rb = pk_mad_u16_lane<0>(b_rb, w32[j >> 1], pk_mad_u16_lane<0>(a_rb, iw32[j >> 1], 0u));
+          ga = pk_mad_u16_lane<0>(b_ga, w32[j >> 1], pk_mad_u16_lane<0>(a_ga, iw32[j >> 1], 0u));
+        }
+        row[4 * h + j] = perm(ga, rb, 0x07030501u);  // R, G, B, A = the high bytes of rb.lo, ga.lo, rb.hi, ga.hi
         if (j < 3) {
           ICAMD_UNROLL
           for (int v = 0; v < 4; ++v) P[v] += D[v];
         }
       }
     }
+    emit(y, row);
   }
+}
+ICAMD_DEV void decode_pvrtc2_block_expanded(const uint32_t C[3][3][4], const uint32_t mod[9], const uint32_t col[9],
+                                            uint32_t px[32]) {
+  decode_pvrtc2_block_rows(C, mod, col, [&](int y, const uint32_t row[8]) {
+    ICAMD_UNROLL
+    for (int x = 0; x < 8; ++x) px[8 * y + x] = row[x];
+  });
 }
 
 ICAMD_DEV void decode_pvrtc2_block(const uint32_t mod[9], const uint32_t col[9], uint32_t px[32]) {

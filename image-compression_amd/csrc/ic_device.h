@@ -188,6 +188,7 @@ struct __attribute__((packed, aligned(1))) U2 { uint32_t x, y; };
 #if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV U4 load_stream(const U4 *p) { return *p; }
 ICAMD_DEV U3 load_stream(const U3 *p) { return *p; }
+ICAMD_DEV U2 load_stream(const U2 *p) { return *p; }
 #else
 typedef uint32_t icamd_u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t icamd_u32x3_u __attribute__((ext_vector_type(3), aligned(1)));
@@ -201,6 +202,15 @@ ICAMD_DEV U3 load_stream(const U3 *p) {
   const icamd_u32x3_u v = __builtin_nontemporal_load(reinterpret_cast<const icamd_u32x3_u *>(p));
   U3 r = { v.x, v.y, v.z };
   return r;
+}
+ICAMD_DEV U2 load_stream(const U2 *p) {
+  const icamd_u32x2_u v = __builtin_nontemporal_load(reinterpret_cast<const icamd_u32x2_u *>(p));
+  U2 r = { v.x, v.y };
+  return r;
+}
+ICAMD_DEV void store_stream12(void *p, uint32_t a, uint32_t b, uint32_t c) {
+  const icamd_u32x3_u v = { a, b, c };
+  __builtin_nontemporal_store(v, reinterpret_cast<icamd_u32x3_u *>(p));
 }
 // 8- and 16-byte block stores (no alignment assumed: the caller owns the output pointer)
 ICAMD_DEV void store_stream8(void *p, uint32_t a, uint32_t b) {
