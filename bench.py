@@ -38,6 +38,7 @@ import argparse
 import json
 import math
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -760,7 +761,10 @@ def timed_steps(ctx, step, steps, warmup, precondition_seconds=0.0, stream=None)
     return elapsed, kernel_ms
 
 
-def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=180):
+_LIVE_TRAFFIC_OFF = []  # set to [reason] by the first failed live measurement: the remaining legs go straight to the committed profile
+
+
+def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
     """roofline.traffic measured IN THIS RUN: HBM bytes per launch = FETCH_SIZE * 2 + WRITE_SIZE (KiB -> bytes; the x 2 is the
     gfx950 correction for wide streaming reads, MI355X_MICROARCH.md section HBM), each counter from its own rocprofv3 --pmc pass
     (they cannot share one) over a child process that launches exactly this workload three times (`--traffic-child`); kernels
@@ -769,6 +773,8 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=180):
     import glob
     import shutil
     import tempfile
+    if _LIVE_TRAFFIC_OFF:
+        return None, _LIVE_TRAFFIC_OFF[0]
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
     if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
@@ -782,7 +788,14 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=180):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
                    os.path.abspath(__file__), "--traffic-child", "--workload", workload, "--size", str(size), "--batch", str(batch),
                    "--content", content, "--etc-strategy", str(etc_strategy)]
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+            # own process group: a pass that overruns is killed WITH the child it started (rocprofv3 is a wrapper)
+            r = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp", start_new_session=True)
+            try:
+                r.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(r.pid, signal.SIGKILL)
+                r.wait()
+                raise
             per_kernel = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -790,10 +803,12 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=180):
                         if row["Kernel_Name"].startswith("icamd_") and row["Counter_Name"] == ctr:
                             per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
             if r.returncode != 0 or not per_kernel:
-                return None, "rocprofv3 --pmc %s pass failed (rc %s)" % (ctr, r.returncode)
+                _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass failed (rc %s)" % (ctr, r.returncode))
+                return None, _LIVE_TRAFFIC_OFF[0]
             kib[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
-        except Exception as e:  # a diagnostic: never fatal
-            return None, "rocprofv3 --pmc %s pass: %s: %s" % (ctr, type(e).__name__, e)
+        except Exception as e:  # a diagnostic: never fatal, and never paid for twice
+            _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass: %s: %s" % (ctr, type(e).__name__, str(e)[:200]))
+            return None, _LIVE_TRAFFIC_OFF[0]
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return int(kib["FETCH_SIZE"] * 2048 + kib["WRITE_SIZE"] * 1024), \
