@@ -210,3 +210,23 @@ def test_pvrtc4_onepass_kernel_ring_protocol_as_compiled(tmp_path):
     waits = [re.sub(r"\s+", " ", l.strip()) for l in walk if "s_waitcnt" in l and "vmcnt" in l]
     assert sum("global_load_lds_dwordx4" in l for l in walk) == 4 and waits == ["s_waitcnt vmcnt(2)"] * 4, waits
     assert sum(bool(re.match(r"\s+s_barrier", l)) for l in walk) == 1
+
+
+def test_pvrtc_decode_tile_kernel_writes_whole_lines(tmp_path):
+    """r05: the decoder's bound was its store pattern.  As compiled: each pixel row of a wave goes through the
+    per-wave LDS turn (two 16-byte writes, two 16-byte reads 1 KiB apart) and leaves as two NON-TEMPORAL 16-byte stores -- eight
+    per block, none plain --, the LDS read of a row follows its writes in program order, nothing spills, and the kernel keeps
+    at least 7 waves per SIMD (72 VGPRs)."""
+    text = _asm("decode_kernels.hip", tmp_path)
+    name = "icamd_pvrtc2_decode_tile_kernel"
+    meta = _kernel_meta(text, name)
+    assert meta["scratch"] == 0 and meta["vgprs"] <= 72, meta
+    ops = [l.split(";")[0].strip() for l in _body(text, name)]
+    stores = [l for l in ops if l.startswith("global_store")]
+    assert len(stores) == 8 and all(l.startswith("global_store_dwordx4") and l.endswith(" nt") for l in stores), stores
+    seq = [("w" if l.startswith("ds_write_b128") else "r" if l.startswith("ds_read_b128") else "s")
+           for l in ops if l.startswith(("ds_write_b128", "ds_read_b128", "global_store_dwordx4"))]
+    tail = "".join(seq)[-24:]   # the four rows: (write, write, read, read, store, store) each; the colour pairs' reads come first
+    assert tail == "wwrrss" * 4, "".join(seq)
+    reads = [l for l in ops if l.startswith("ds_read_b128")][-8:]
+    assert sum("offset:1024" in l for l in reads) == 4, reads
