@@ -539,7 +539,7 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     }
 
 
-def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, kernel_ms, clock_mhz, preset=None):
+def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, kernel_ms, clock_mhz, preset=None, live_insts=None):
     """Integer-VALU issue fraction of the sustained run, from measured quantities only:
       executed VALU wave-instructions per kernel  -- SQ_INSTS_VALU of the committed PMC profile of EXACTLY this workload /
                                                     content / ETC strategy (profiles/valu_insts.json);
@@ -549,14 +549,20 @@ def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, ker
                                                     that rate, weighted with each kernel's static mix (profiles/*_isa.json);
       clock                                       -- the shader clock the probe measured during this run (or 2 400 MHz
                                                     nominal when the probe is unavailable, which is then said so)."""
+    mpix = pixels_per_launch / 1e6
+    vi = None
+    if live_insts:  # r05: counted in this run by live_traffic()'s third pass, over exactly this launch shape and content
+        total = sum(live_insts.values())
+        vi = {"valu_wave_insts_per_Mpixel": total / mpix, "per_kernel_valu_wave_insts_per_Mpixel": {k: v / mpix for k, v in live_insts.items()},
+              "valu_wave_insts_per_block_lane": round(total * 64.0 / (pixels_per_launch / (32.0 if codec == 3 else 16.0)), 1),
+              "profile": "measured in this run (rocprofv3 --pmc SQ_INSTS_VALU over a child process launching this workload three times)"}
     vpath = os.path.join(ROOT, "profiles", "valu_insts.json")
-    if not os.path.exists(vpath):
-        return None
-    with open(vpath) as f:
-        table = json.load(f)
-        # a profile of EXACTLY the preset's launch shape and content first (c4: the ETC1 search is content- and size-dependent)
-        vi = (table.get("preset:%s/%s/s%d" % (preset, content, etc_strategy if codec == 2 else 0)) if preset else None) or \
-            table.get("%s/%s/s%d" % (workload, content, etc_strategy if codec == 2 else 0))
+    if vi is None and os.path.exists(vpath):
+        with open(vpath) as f:
+            table = json.load(f)
+            # a profile of EXACTLY the preset's launch shape and content first (c4: the ETC1 search is content- and size-dependent)
+            vi = (table.get("preset:%s/%s/s%d" % (preset, content, etc_strategy if codec == 2 else 0)) if preset else None) or \
+                table.get("%s/%s/s%d" % (workload, content, etc_strategy if codec == 2 else 0))
     if not vi:
         return None
     isa = {}
@@ -565,7 +571,6 @@ def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, ker
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 isa = json.load(f).get("kernels", {})
             break
-    mpix = pixels_per_launch / 1e6
     per_kernel = vi.get("per_kernel_valu_wave_insts_per_Mpixel") or {}
     clocks, detail = 0.0, {}
     if per_kernel:
@@ -761,6 +766,7 @@ def timed_steps(ctx, step, steps, warmup, precondition_seconds=0.0, stream=None)
     return elapsed, kernel_ms
 
 
+LIVE_VALU_INSTS = {}    # (workload, size, batch, content, etc_strategy) -> {kernel: SQ_INSTS_VALU per launch}, filled by live_traffic()
 _LIVE_TRAFFIC_OFF = []  # set to [reason] by the first failed live measurement: the remaining legs go straight to the committed profile
 
 
@@ -782,7 +788,7 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
     csv.field_size_limit(1 << 30)
     kib = {}
     env = dict(os.environ, TMPDIR="/tmp")
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="icamd_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
@@ -806,6 +812,8 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
                 _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass failed (rc %s)" % (ctr, r.returncode))
                 return None, _LIVE_TRAFFIC_OFF[0]
             kib[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
+            if ctr == "SQ_INSTS_VALU":  # executed VALU wave-instructions per launch, per kernel: valu_fraction()'s input
+                LIVE_VALU_INSTS[(workload, size, batch, content, etc_strategy)] = {k: sum(v) / len(v) for k, v in per_kernel.items()}
         except Exception as e:  # a diagnostic: never fatal, and never paid for twice
             _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass: %s: %s" % (ctr, type(e).__name__, str(e)[:200]))
             return None, _LIVE_TRAFFIC_OFF[0]
@@ -813,7 +821,7 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
             shutil.rmtree(d, ignore_errors=True)
     return int(kib["FETCH_SIZE"] * 2048 + kib["WRITE_SIZE"] * 1024), \
         "measured in this run: FETCH_SIZE * 2 + WRITE_SIZE from two separate rocprofv3 --kernel-trace --pmc passes over a child " \
-        "process launching this workload three times (per launch, kernels of a step summed)"
+        "process launching this workload three times (per launch, kernels of a step summed); a third pass counts SQ_INSTS_VALU"
 
 
 def preset_traffic(preset, workload, size, batch):
@@ -895,7 +903,8 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
         # the clock this figure was taken at (DXT5 moves 835 <-> 1 264 Gpix/s with it, r04) and the VALU issue fraction
         mhz = clock_under_load(torch, pkg, step, kernel_ms, max(steps, int(30.0 / max(kernel_ms, 1e-3)))) if ctx.on_gpu else None
         res["roofline"]["effective_clock_MHz"] = mhz
-        vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, kernel_ms, mhz, preset=name)
+        vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, kernel_ms, mhz, preset=name,
+                           live_insts=LIVE_VALU_INSTS.get((cfg["workload"], size, batch, content, strategy)))
         if vf:
             res["roofline"].update({k: vf[k] for k in ("valu_frac", "valu_wave_insts_per_block", "valu_profile", "valu_clock_MHz")})
         if verify:
@@ -1316,7 +1325,8 @@ def main():
                 if mhz:
                     result["roofline"]["effective_clock_MHz"] = mhz
                 vf = valu_fraction(args.workload, args.content, args.etc_strategy, codec, pixels_per_step_rank,
-                                   sus["median_ms_last_20pct"], mhz)
+                                   sus["median_ms_last_20pct"], mhz,
+                                   live_insts=LIVE_VALU_INSTS.get((args.workload, size, batch, args.content, args.etc_strategy)))
                 if vf:
                     result["roofline"].update(vf)
             except Exception as e:
@@ -1350,11 +1360,11 @@ def main():
                     for content in ("smooth", "flat"):
                         try:
                             r = preset_leg(ctx, pkg, sharding, name, max(2, args.extra_steps // 2), content=content,
-                                           verify=not args.no_verify, gather=False)
+                                           verify=not args.no_verify, gather=False, live=not args.no_live_traffic)
                             other[content] = {k: r.get(k) for k in ("value", "unit", "ms_per_step", "steps", "parity", "data")}
                             rf = r.get("roofline") or {}
                             other[content].update({k: rf.get(k) for k in ("frac", "valu_frac", "effective_clock_MHz", "kernel_ms",
-                                                                           "valu_wave_insts_per_block")})
+                                                                           "valu_wave_insts_per_block", "valu_profile", "traffic")})
                         except Exception as e:
                             other[content] = {"error": "%s: %s" % (type(e).__name__, e)}
                     configs[name]["other_contents"] = other
