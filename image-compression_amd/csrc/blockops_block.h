@@ -54,6 +54,32 @@ ICAMD_DEV Out8 etc1_pad_block(uint32_t w0, uint32_t w1, int kind, uint32_t strat
   return encode_etc1_block(px, strategy);
 }
 
+// The same with four lanes per pad block (kSmallerError; etc1_block.h encode_etc1_block_quad): every lane of the quad decodes
+// the source block and builds the pad block's pixels, the search is split.  t = lane & 3; *writes: this lane stores.
+#if defined(ICAMD_HOST_EMULATION)
+ICAMD_DEV Out8 etc1_pad_block_quad(uint32_t w0, uint32_t w1, int kind) {
+#else
+ICAMD_DEV Out8 etc1_pad_block_quad(uint32_t w0, uint32_t w1, int kind, uint32_t t, bool *writes) {
+#endif
+  uint32_t src[16], px[16];
+  decode_etc1(w0, w1, src);
+#if !defined(ICAMD_HOST_EMULATION)
+  if (kind == kPadCorner) { *writes = t == 0u; return etc1_solid_block(src[15]); }
+#else
+  if (kind == kPadCorner) return etc1_solid_block(src[15]);
+#endif
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    ICAMD_UNROLL
+    for (int x = 0; x < 4; ++x) px[4 * y + x] = kind == kPadColumn ? src[4 * y + 3] : src[12 + x];
+  }
+#if defined(ICAMD_HOST_EMULATION)
+  return encode_etc1_block_quad(px);
+#else
+  return encode_etc1_block_quad(px, t, writes);
+#endif
+}
+
 // Average4ColorsFast (color_util.h:335-380) on packed pixels: per channel (a+b+c+d)/4.
 ICAMD_DEV uint32_t average4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   const uint32_t m = 0x00ff00ffu;

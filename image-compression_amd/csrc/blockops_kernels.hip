@@ -1,5 +1,6 @@
 // blockops_kernels.hip -- Pad / Downsample / DXT1->ETC1 transcode kernels: one output
 // block per lane, coalesced 8/16-byte block loads and stores.  See blockops_block.h for the per-block math.
+#include <cstdlib>
 #include "blockops_block.h"
 #include "ic_launch.h"
 #include "ic_amd.h"
@@ -57,8 +58,29 @@ template <int CODEC, int STRATEGY, int PART>
 __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
   uint32_t img = 0;
   if (P.n_images > 1) {
-    img = fastdiv(k, P.div_out_per_image);
-    k -= img * P.out_per_image;
+    if (PART == 3) {  // work items are quad lanes of pad blocks
+      img = fastdiv(k, P.div_border_lanes_per_image);
+      k -= img * P.border_lanes_per_image;
+    } else {
+      img = fastdiv(k, P.div_out_per_image);
+      k -= img * P.out_per_image;
+    }
+  }
+  if (PART == 3) {  // PART 2 with four lanes per pad block (kSmallerError): work item k = 4 * border block + quad lane
+    const uint32_t t = k & 3u;
+    k >>= 2;
+    const uint32_t dc = P.out_cols - P.in_cols, right = P.in_rows * dc;
+    uint32_t r, c;
+    if (k < right) { r = k / dc; c = P.in_cols + (k - r * dc); }
+    else { const uint32_t j = k - right; r = P.in_rows + j / P.out_cols; c = j - (r - P.in_rows) * P.out_cols; }
+    const bool in_rows = r < P.in_rows, in_cols = c < P.in_cols;
+    const uint32_t sr = in_rows ? r : P.in_rows - 1, sc = in_cols ? c : P.in_cols - 1;
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(P.src + (size_t)img * P.src_image_stride) + ((size_t)sr * P.in_cols + sc) * 2;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(P.dst + (size_t)img * P.dst_image_stride) + ((size_t)r * P.out_cols + c) * 2;
+    bool writes = false;
+    const Out8 o = etc1_pad_block_quad(s[0], s[1], in_rows ? kPadColumn : (in_cols ? kPadRow : kPadCorner), t, &writes);
+    if (writes) { dst[0] = o.lo; dst[1] = o.hi; }
+    return;
   }
   if (PART == 2) {
     const uint32_t dc = P.out_cols - P.in_cols, right = P.in_rows * dc;
@@ -184,6 +206,18 @@ ICAMD_PAD_KERNEL(etc1_border_split_h, ICAMD_ETC1, 0, 2)
 ICAMD_PAD_KERNEL(etc1_border_split_v, ICAMD_ETC1, 1, 2)
 ICAMD_PAD_KERNEL(etc1_border, ICAMD_ETC1, 2, 2)
 ICAMD_PAD_KERNEL(etc1_border_heuristic, ICAMD_ETC1, 3, 2)
+// kSmallerError (r05): four lanes per pad block, and -- the split search needs 61 VGPRs where the whole one needed 121, so the
+// copy no longer loses occupancy to it -- in the SAME launch as the copy of the image's own blocks: the first border_wgs
+// workgroups are the pad blocks (they start first and are the long ones), the others copy.  One launch per Pad call.
+extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pad_etc1_quad_kernel(BlockOpParams P) {
+  if (blockIdx.x < P.border_wgs) {
+    const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
+    if (k < P.border_lanes) pad_one<ICAMD_ETC1, 2, 3>(P, k);
+  } else {
+    const uint32_t k = (blockIdx.x - P.border_wgs) * kThreadsPerWorkgroup + threadIdx.x;
+    if (k < P.total_out) pad_one<ICAMD_ETC1, 2, 1>(P, k);
+  }
+}
 ICAMD_DOWNSAMPLE_KERNEL(dxt1, ICAMD_DXT1, 0)
 ICAMD_DOWNSAMPLE_KERNEL(dxt5, ICAMD_DXT5, 0)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
@@ -200,15 +234,31 @@ extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_to
   blocks[k] = make_uint2(o.lo, o.hi);
 }
 
+// A/B switch (ICAMD_PAD_BORDER_QUAD=0: one lane per pad block, the r04 form); read once
+static bool pad_border_quad() {
+  static const bool on = [] { const char *e = getenv("ICAMD_PAD_BORDER_QUAD"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
   if (P.total_out == 0) return hipSuccess;
   const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
   if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_pad_dxt1_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_pad_dxt5_kernel, grid, block, 0, stream, P);
   else if (codec == ICAMD_ETC1) {
+    const uint64_t border = (uint64_t)P.in_rows * (P.out_cols - P.in_cols) + (uint64_t)(P.out_rows - P.in_rows) * P.out_cols;
+    if (border && P.etc_strategy != 0u && P.etc_strategy != 1u && P.etc_strategy != 3u && pad_border_quad() &&
+        border * 4u * P.n_images < (1ull << 31)) {
+      BlockOpParams Q = P;
+      Q.border_lanes_per_image = (uint32_t)border * 4u;
+      Q.div_border_lanes_per_image = make_fastdiv(Q.border_lanes_per_image);
+      Q.border_lanes = Q.border_lanes_per_image * P.n_images;
+      Q.border_wgs = (Q.border_lanes + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup;
+      hipLaunchKernelGGL(icamd_pad_etc1_quad_kernel, dim3(grid.x + Q.border_wgs), block, 0, stream, Q);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL(icamd_pad_etc1_copy_kernel, grid, block, 0, stream, P);
     BlockOpParams B = P;  // the pad blocks only: right of the image, then below it
-    const uint64_t border = (uint64_t)P.in_rows * (P.out_cols - P.in_cols) + (uint64_t)(P.out_rows - P.in_rows) * P.out_cols;
     B.out_per_image = (uint32_t)border;
     B.div_out_per_image = make_fastdiv(border ? (uint32_t)border : 1u);
     B.total_out = (uint32_t)(border * P.n_images);

@@ -397,17 +397,9 @@ ICAMD_DEV EtcSubResult heuristic_codeword(const uint32_t px[16], const EtcBase &
   return r;
 }
 
-struct EtcFlipResult {
-  int32_t score;          // sum of both sub-block scores (Sum over the 16 pixels of max_k E)
-  uint32_t hi;            // high word (flip, diff, codewords, colours), etc.cc:43-61
-  uint32_t f0, f1;        // index fields of sub-block 0 / 1
-};
-
-// FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
-template <int FLIP, bool TIER = false, bool PRUNE = true, bool SKIP = false>
-ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
-                                    const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP,
-                                    bool skip = false, const uint32_t (*packed)[3][2] = nullptr) {
+// The base colours of a partition's two sub-blocks from their channel sums s0 / s1 (R, G, B), and the high word's
+// flip / diff / colour bits (etc.cc:460-521): differential 5-5-5 + 3-bit deltas when every delta fits, else individual 4-4-4.
+ICAMD_DEV uint32_t etc1_partition_bases(const uint32_t s0[3], const uint32_t s1[3], uint32_t flip_bit, uint32_t b0[3], uint32_t b1[3]) {
   // ComputeAverageColor (etc.cc:299-312): sum/8; QuantizeRgbFast<5>: >>3; <4>: >>4 (color_util.h:142-148)
   uint32_t q5a[3], q5b[3];
   bool diff_mode = true;
@@ -419,7 +411,6 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
     diff_mode = diff_mode && d >= -4 && d <= 3;
   }
   uint32_t hi = flip_bit;
-  uint32_t b0[3], b1[3];  // decoded base colours (what the decoder will reconstruct)
   if (diff_mode) {
     hi |= 2u;
     ICAMD_UNROLL
@@ -438,6 +429,22 @@ ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[1
       b1[ch] = qb * 17u;
     }
   }
+  return hi;
+}
+
+struct EtcFlipResult {
+  int32_t score;          // sum of both sub-block scores (Sum over the 16 pixels of max_k E)
+  uint32_t hi;            // high word (flip, diff, codewords, colours), etc.cc:43-61
+  uint32_t f0, f1;        // index fields of sub-block 0 / 1
+};
+
+// FindBestSubblockEncoding (etc.cc:460-542).  s0[], s1[] = channel sums (R,G,B) of the two sub-blocks.
+template <int FLIP, bool TIER = false, bool PRUNE = true, bool SKIP = false>
+ICAMD_DEV EtcFlipResult encode_flip(const uint32_t px[16], const uint32_t psum[16], const uint32_t s0[3],
+                                    const uint32_t s1[3], bool heuristic, uint32_t flip_bit = (uint32_t)FLIP,
+                                    bool skip = false, const uint32_t (*packed)[3][2] = nullptr) {
+  uint32_t b0[3], b1[3];  // decoded base colours (what the decoder will reconstruct)
+  const uint32_t hi = etc1_partition_bases(s0, s1, flip_bit, b0, b1);
   EtcBase e0 = { b0[0] << 24 | b0[2] << 8, b0[1] << 8 };
   EtcBase e1 = { b1[0] << 24 | b1[2] << 8, b1[1] << 8 };
   EtcSubResult r0, r1;
@@ -677,6 +684,107 @@ ICAMD_DEV Out8 encode_etc1_block(const uint32_t px[16], uint32_t strategy, bool 
   Out8 o = { perm(0u, res.hi, 0x00010203u), perm(0u, lo, 0x00010203u) };
   return o;
 }
+
+// ---- kSmallerError with FOUR lanes per block (r05) -------------------------------------------------------------------
+// For launches of FEW blocks that each need the whole search -- the pad blocks of an ETC1 Pad: 4 352 of them around a 4096^2
+// texture, one per lane that is 65 waves of ~3 800 dependent instructions on 65 of the chip's 1 024 SIMDs.  The four searches
+// of EncodeEtc1Block (etc.cc:575-583: two partitions x two sub-blocks) are independent once the partition's base colours are
+// known, so lane t of a quad takes partition f = t >> 1, sub-block s = t & 1: it computes ITS partition's bases (both lanes of
+// a partition do: a few dozen instructions), gathers its eight pixels into the (sub-block 0, j) slots and runs the one search
+// every lane runs (search_codewords<2, 0>: the per-lane-partition form kHeuristic already uses).  The results meet by quad
+// permutes (etc1_quad_finish): same keys, same tie rules, same bytes as encode_etc1_block.
+struct EtcQuadPart {
+  int32_t score;         // Sum over the lane's eight pixels of max_k E
+  uint32_t cw, fields;   // its sub-block's codeword and index fields
+  uint32_t hi;           // its partition's high word without the codewords (equal in both lanes of a partition)
+};
+template <bool TIER = false, bool PRUNE = true>
+ICAMD_DEV EtcQuadPart etc1_quad_part(const uint32_t px[16], uint32_t f, uint32_t s) {
+  uint32_t qs[4][3];  // per-quadrant channel sums; quadrant q = 2*(y>=2) + (x>=2)
+  ICAMD_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    qs[q][0] = qs[q][1] = qs[q][2] = 0;
+    ICAMD_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t p = px[4 * (2 * (q >> 1) + (i >> 1)) + 2 * (q & 1) + (i & 1)];
+      qs[q][0] = udot4(p, 0x00000001u, qs[q][0]);
+      qs[q][1] = udot4(p, 0x00000100u, qs[q][1]);
+      qs[q][2] = udot4(p, 0x00010000u, qs[q][2]);
+    }
+  }
+  uint32_t sa[3], sb[3];  // sub-blocks 0 / 1 of the lane's partition: left | right (f = 0) or top | bottom (f = 1)
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    sa[ch] = qs[0][ch] + (f ? qs[1][ch] : qs[2][ch]);
+    sb[ch] = qs[3][ch] + (f ? qs[2][ch] : qs[1][ch]);
+  }
+  uint32_t b0[3], b1[3], bm[3], sm[3];
+  EtcQuadPart out;
+  out.hi = etc1_partition_bases(sa, sb, f, b0, b1);
+  ICAMD_UNROLL
+  for (int ch = 0; ch < 3; ++ch) {
+    bm[ch] = s ? b1[ch] : b0[ch];
+    sm[ch] = s ? sb[ch] : sa[ch];
+  }
+  uint32_t pl[16], ps[16];
+  ICAMD_UNROLL
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t v0 = s ? px[sub_pixel<0, 1>(j)] : px[sub_pixel<0, 0>(j)], v1 = s ? px[sub_pixel<1, 1>(j)] : px[sub_pixel<1, 0>(j)];
+    pl[j] = f ? v1 : v0;
+    ps[j] = udot4(pl[j], 0x00020202u, 0u);
+    pl[8 + j] = 0u; ps[8 + j] = 0u;  // (never read: search_codewords<2, 0> looks at slots 0..7 only)
+  }
+  const EtcBase e = { bm[0] << 24 | bm[2] << 8, bm[1] << 8 };
+  const EtcSubResult r = search_codewords<2, 0, TIER, PRUNE, false>(pl, ps, e, bm, sm);
+  out.score = r.score; out.cw = r.cw; out.fields = r.fields;
+  return out;
+}
+// mine: this lane's part; mate: the other sub-block of the same partition; other_score: the other partition's total.
+// *writes: this lane holds the block (sub-block 0 of the winning partition).  error_lr <= error_tb keeps flip = 0 (etc.cc:583).
+ICAMD_DEV Out8 etc1_quad_finish(const EtcQuadPart &mine, const EtcQuadPart &mate, int32_t other_score, uint32_t f, uint32_t s,
+                                bool *writes) {
+  const int32_t total = mine.score + mate.score;
+  const int32_t score_lr = f ? other_score : total, score_tb = f ? total : other_score;
+  const bool flip = !(score_lr >= score_tb);
+  *writes = s == 0u && (f != 0u) == flip;
+  const uint32_t hi = mine.hi | mine.cw << 5 | mate.cw << 2;
+  const uint32_t lo = assemble_indices(mine.fields, mate.fields, flip);
+  Out8 o = { perm(0u, hi, 0x00010203u), perm(0u, lo, 0x00010203u) };
+  return o;
+}
+#if defined(ICAMD_HOST_EMULATION)
+// the four lanes of a quad, one after the other (the host build has no lanes): what the quad kernels compute
+ICAMD_DEV Out8 encode_etc1_block_quad(const uint32_t px[16]) {
+  EtcQuadPart part[4];
+  for (uint32_t t = 0; t < 4; ++t) part[t] = etc1_quad_part(px, t >> 1, t & 1u);
+  Out8 out = { 0u, 0u };
+  int writers = 0;
+  for (uint32_t t = 0; t < 4; ++t) {
+    bool writes = false;
+    const Out8 o = etc1_quad_finish(part[t], part[t ^ 1u], part[t ^ 2u].score + part[t ^ 3u].score, t >> 1, t & 1u, &writes);
+    if (writes) { out = o; ++writers; }
+  }
+  if (writers != 1) { out.lo = 0xdeadbeefu; out.hi = (uint32_t)writers; }  // (a test would see it)
+  return out;
+}
+#else
+// quad permutes (DPP quad_perm [1,0,3,2] / [2,3,0,1]): lane t reads lane t ^ 1 / t ^ 2 of its quad
+ICAMD_DEV uint32_t quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xb1, 0xf, 0xf, true); }
+ICAMD_DEV uint32_t quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4e, 0xf, 0xf, true); }
+// Called by ALL FOUR lanes of a quad (t = lane & 3) with the same pixels.  *writes: this lane stores the result.
+ICAMD_DEV Out8 encode_etc1_block_quad(const uint32_t px[16], uint32_t t, bool *writes) {
+  const uint32_t f = t >> 1, s = t & 1u;
+  const EtcQuadPart mine = etc1_quad_part(px, f, s);
+  EtcQuadPart mate;
+  mate.score = (int32_t)quad_xor1((uint32_t)mine.score);
+  mate.cw = quad_xor1(mine.cw);
+  mate.fields = quad_xor1(mine.fields);
+  mate.hi = mine.hi;
+  const int32_t total = mine.score + mate.score;
+  const int32_t other = (int32_t)quad_xor2((uint32_t)total);
+  return etc1_quad_finish(mine, mate, other, f, s, writes);
+}
+#endif
 
 }  // namespace icamd
 #endif  // ICAMD_ETC1_BLOCK_H_

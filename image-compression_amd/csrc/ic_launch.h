@@ -112,6 +112,10 @@ struct BlockOpParams {
   uint32_t n_images = 1, out_per_image = 0;
   uint64_t src_image_stride = 0, dst_image_stride = 0;  // bytes
   FastDiv div_out_per_image = { 0, 0, 1 };
+  // ETC1 Pad, kSmallerError, ONE launch (r05): the first border_wgs workgroups are the pad blocks' quad lanes
+  // (border_lanes = 4 * pad blocks over all images, border_lanes_per_image of them per image), the rest copy the grid
+  uint32_t border_wgs = 0, border_lanes = 0, border_lanes_per_image = 0;
+  FastDiv div_border_lanes_per_image = { 0, 0, 1 };
 };
 hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream);
 hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream);

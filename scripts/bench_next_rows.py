@@ -25,8 +25,18 @@ stream = torch.cuda.current_stream()
 sh = ctypes.c_void_p(stream.cuda_stream)
 
 def timeit(fn, reps=20):
-    for _ in range(3): fn()
+    """Seconds per call in the steady state: like bench.py's preconditioning (the first launches after an idle period
+    run 10-30 % slower than the steady state of the same kernel), 0.25 s of untimed calls first, then at least `reps` calls and
+    at least 60 ms between two events on the launch stream."""
+    import time
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); n0 = 0
+    while time.perf_counter() - t0 < 0.25:
+        fn(); n0 += 1
+        if n0 % 8 == 0: torch.cuda.synchronize()
     torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / max(n0, 1)
+    reps = max(reps, min(2000, int(0.06 / max(per, 1e-6))))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(reps): fn()

@@ -115,7 +115,13 @@ static void emul_pad_t(int strategy, uint32_t orows, uint32_t ocols, uint32_t pr
       uint32_t *d = reinterpret_cast<uint32_t *>(out) + ((size_t)r * pcols + c) * W;
       if (in_rows && in_cols) { memcpy(d, s, W * 4); continue; }
       const int kind = in_rows ? kPadColumn : (in_cols ? kPadRow : kPadCorner);
-      if (CODEC == 2) { Out8 o = etc1_pad_block(s[0], s[1], kind, (uint32_t)strategy); d[0] = o.lo; d[1] = o.hi; }
+      if (CODEC == 2) {
+        Out8 o = etc1_pad_block(s[0], s[1], kind, (uint32_t)strategy); d[0] = o.lo; d[1] = o.hi;
+        if (strategy == 2) {  // the four-lanes-per-block form of the Pad border kernel must give the same bytes
+          const Out8 q = etc1_pad_block_quad(s[0], s[1], kind);
+          if (q.lo != o.lo || q.hi != o.hi) { d[0] = 0xbad0bad0u; d[1] = q.lo ^ q.hi; }
+        }
+      }
       else if (CODEC == 0) { d[0] = s[0]; d[1] = dxt_pad_color_bits(s[1], kind); }
       else {
         uint32_t lo24 = s[0] >> 16 | (s[1] & 0xffu) << 16, hi24 = s[1] >> 8;

@@ -625,6 +625,44 @@ def test_blockops_match_oracle(pkg):
     assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)
 
 
+def test_etc1_pad_quad_lanes_and_one_lane_forms_match_oracle(pkg):
+    """r05: the kSmallerError Pad runs as ONE launch whose first workgroups are the pad blocks with FOUR lanes each
+    (encode_etc1_block_quad).  Arbitrary ETC1 block words (saturated bases, clamping codewords, partition ties), batched
+    with an image stride, rows-only / columns-only / both borders; and the r04 form (one lane per pad block, two launches:
+    ICAMD_PAD_BORDER_QUAD=0, read once per process -> a child process) on the same inputs."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import ic_amd_loader, ic_testlib as T
+pkg = ic_amd_loader.load_package()
+g = np.random.Generator(np.random.PCG64(41))
+bad = 0
+for trial in range(6):
+    h, w = (64, 128) if trial < 4 else (8, 4)
+    raw = g.integers(0, 256, size=(h // 4) * (w // 4) * 8, dtype=np.uint8)
+    if trial in (2, 3): raw = (raw & (0xc0 if trial == 2 else 0x81)).astype(np.uint8)
+    for (ph, pw) in [(h + 8, w + 12), (h, w + 4), (h + 4, w)]:
+        got = pkg.pad_host(T.ETC, T.RGB, raw.tobytes(), h, w, ph, pw, 2)
+        bad += got != T.oracle_pad(T.ETC, T.RGB, raw.tobytes(), h, w, ph, pw, 2)
+n, h, w, ph, pw = 3, 32, 64, 40, 72
+grids = [g.integers(0, 256, size=(h // 4) * (w // 4) * 8, dtype=np.uint8) for _ in range(n)]
+src = torch.zeros((n, grids[0].size + 40), dtype=torch.uint8, device="cuda")
+for i, q in enumerate(grids): src[i, :q.size] = torch.from_numpy(q).cuda()
+out = pkg.pad_batch_device(T.ETC, T.RGB, src, h, w, ph, pw, etc_strategy=2)  # (image stride = the tensor's row: 40 spare bytes)
+torch.cuda.synchronize()
+for i, q in enumerate(grids):
+    bad += out[i].cpu().numpy().tobytes() != T.oracle_pad(T.ETC, T.RGB, q.tobytes(), h, w, ph, pw, 2)
+print("BAD", bad)
+""" % (T.ROOT, T.ROOT)
+    for quad in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICAMD_PAD_BORDER_QUAD=quad), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("BAD 0"), (quad, r.stdout[-300:], r.stderr[-600:])
+
+
 def test_batched_block_operations_match_oracle(pkg):
     """r05: icamd_pad_batch_device / icamd_copy_subimage_batch_device / icamd_create_solid_batch_device -- n equally shaped
     grids per launch (padded image strides on the source side), every image against the oracle's per-image result; and the

@@ -230,3 +230,14 @@ def test_pvrtc_decode_tile_kernel_writes_whole_lines(tmp_path):
     assert tail == "wwrrss" * 4, "".join(seq)
     reads = [l for l in ops if l.startswith("ds_read_b128")][-8:]
     assert sum("offset:1024" in l for l in reads) == 4, reads
+
+
+def test_etc1_pad_quad_kernel_keeps_the_copy_at_full_occupancy(tmp_path):
+    """r05: the kSmallerError Pad is one launch -- pad blocks (four lanes each) and the copy of the image's own blocks in the same
+    kernel.  That only works while the split search stays within 64 VGPRs (8 waves per SIMD for the copy workgroups; r04's
+    whole search took 121 and was split off into its own launch for that reason), without scratch."""
+    text = _asm("blockops_kernels.hip", tmp_path)
+    meta = _kernel_meta(text, "icamd_pad_etc1_quad_kernel")
+    assert meta["scratch"] == 0 and meta["vgprs"] <= 64, meta
+    body = [l.split(";")[0].strip() for l in _body(text, "icamd_pad_etc1_quad_kernel")]
+    assert sum(l.startswith("v_mov_b32_dpp") and "quad_perm" in l for l in body) >= 3, "the quad exchange is gone"

@@ -222,6 +222,20 @@ def test_blockops_math_matches_oracle(emul):
             out = np.zeros(max(len(want) if want else 0, bb), np.uint8)
             ok = emul.emul_downsample(codec, strategy, h, w, b.ctypes.data, out.ctypes.data)
             assert (out[:len(want)].tobytes() if ok else None) == want, (codec, h, w)
+    # r05: Pad of ARBITRARY ETC1 block words with kSmallerError -- the border kernel's four-lanes-per-block search
+    # (encode_etc1_block_quad; the emulation runs it next to the one-lane form and poisons the output on a difference) against
+    # the oracle: saturated bases, clamping codewords, individual and differential blocks, ties between the partitions
+    g = np.random.Generator(np.random.PCG64(29))
+    for trial in range(8):
+        h, w = 32, 64
+        raw = g.integers(0, 256, size=(h // 4) * (w // 4) * 8, dtype=np.uint8)
+        if trial >= 6:  # few distinct values: equal rows / columns, partition ties
+            raw = (raw & (0xc0 if trial == 6 else 0x81)).astype(np.uint8)
+        for (ph, pw) in [(h + 8, w + 8), (h, w + 4), (h + 4, w)]:
+            want = T.oracle_pad(T.ETC, T.RGB, raw.tobytes(), h, w, ph, pw, 2)
+            out = np.zeros((ph // 4) * (pw // 4) * 8, np.uint8)
+            assert emul.emul_pad(T.ETC1, 2, h, w, ph, pw, raw.ctypes.data, out.ctypes.data)
+            assert out.tobytes() == want, (trial, ph, pw)
     # Downsample of ARBITRARY block words (not encoder output): DXT1 three-colour mode and equal endpoints, DXT5 six-value
     # alpha -- the kernel's palette-plane / quad-selector form (dxt_downsample_2x2) against the oracle's decode-average-encode
     g = np.random.Generator(np.random.PCG64(17))
