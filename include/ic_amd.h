@@ -191,9 +191,9 @@ int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_
 int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
                      const void *d_blocks, uint32_t padded_height, uint32_t padded_width, void *d_out, size_t out_size,
                      void *hip_stream);
-/* Extension (r05), like icamd_downsample_batch_device: n_images equally shaped grids padded in ONE launch (two for ETC1: the
- * copy, then every image's border blocks together -- a single image's ETC1 border is a few thousand dependent searches on an
- * otherwise empty chip).  Image i at d_blocks + i * src_image_stride_bytes -> d_out + i * dst_image_stride_bytes (multiples of 4). */
+/* Extension (r05), like icamd_downsample_batch_device: n_images equally shaped grids padded in ONE launch (ETC1 with
+ * kSplit* / kHeuristic: two -- the copy, then every image's border blocks together; kSmallerError: one, its pad blocks take
+ * four lanes each in the first workgroups of the launch).  Image i at d_blocks + i * src_image_stride_bytes -> d_out + i * dst_image_stride_bytes (multiples of 4). */
 int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_t compressed_height, uint32_t compressed_width,
                            uint32_t n_images, const void *d_blocks, size_t src_image_stride_bytes, uint32_t padded_height,
                            uint32_t padded_width, void *d_out, size_t dst_image_stride_bytes, size_t out_size_per_image,
