@@ -21,4 +21,5 @@ for l in open("gpurun_out/bench_all.jsonl"):
         "| sustained", (d.get("sustained") or {}).get("median_ms_last_20pct"), (d.get("sustained") or {}).get("frac_last_20pct"),
         "clock", ((d.get("clock") or {}).get("last_25pct") or {}).get("shader_MHz"), "single", (d.get("single_image") or {}).get("median_ms_per_call"))
 PY
-python scripts/bench_next_rows.py 2>&1 | tail -12
+# the "next"-row kernels, unprofiled and in the steady state (0.25 s of untimed calls per leg) -> profiles/<round>_next_rows.txt
+python scripts/bench_next_rows.py > gpurun_out/next_rows.txt 2>&1; cat gpurun_out/next_rows.txt

@@ -28,7 +28,14 @@ def timeit(fn, reps=20):
     """Seconds per call in the steady state: like bench.py's preconditioning (the first launches after an idle period
     run 10-30 % slower than the steady state of the same kernel), 0.25 s of untimed calls first, then at least `reps` calls and
     at least 60 ms between two events on the launch stream."""
-    import time
+    if os.environ.get("ICAMD_NEXT_ROWS_QUICK") == "1":  # the profiled passes (gpu_profile_next_rows.sh): few launches, small CSVs
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps): fn()
+        e1.record(stream); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); n0 = 0
     while time.perf_counter() - t0 < 0.25:

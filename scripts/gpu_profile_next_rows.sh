@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_next
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
+export ICAMD_NEXT_ROWS_QUICK=1   # 3 + 20 launches per leg instead of the 0.25 s of preconditioning of the unprofiled run (bench_all.sh)
 CMD="python scripts/bench_next_rows.py"
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o next -- $CMD > "$O/trace.log" 2>&1
