@@ -113,6 +113,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1: do not measure roofline.traffic in this run (two short child runs of the workload under "
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); use the committed profiles/traffic.json instead")
+    ap.add_argument("--watchdog-seconds", type=float, default=480.0,
+                    help="after the headline measurement: if the extra legs (gather, configs, slab -- collectives that have never run "
+                         "between real GPUs) are still going after this long, rank 0 prints the line with what it has and every rank exits 0")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # internal: three launches, no output
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the torch.distributed / RCCL code path (init, barriers, all-reduce, encode->gather region) "
@@ -1219,24 +1222,6 @@ def main():
     pixels_per_step_all = ctx.sum_over_ranks(float(pixels_per_step_rank))
     value = pixels_per_step_all * args.steps / elapsed / 1e6
 
-    # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
-    gather = None
-    probe = None
-    if distributed and not args.no_gather:
-        try:
-            probe = link_probe(ctx)
-        except Exception as e:
-            probe = None
-            print("bench.py: link probe failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
-        try:
-            counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
-                else [(r * batch, (r + 1) * batch) for r in range(world)]
-            counts = [e - b for b, e in counts]
-            gather = gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, args.steps, stream,
-                                   pixels_per_step_all, codec, probe)
-        except Exception as e:  # the encode-only line must survive a failing gather (it is reported, not hidden)
-            gather = {"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)}
-
     tex = "%dx%d %s" % (size, size, "RGBA8" if comps == 4 else "RGB888")
     result = {
         "metric": "Mpixels/s encode (%s, %s)" % (label, tex),
@@ -1255,6 +1240,52 @@ def main():
                    "world_size": dist.get_world_size() if distributed else 1, "visible_gpus": n_dev,
                    "kernel": pkg.kernel_name(codec, comps)},
     }
+    if rank == 0:  # (completed below; present from here on so that a line printed by the watchdog carries it)
+        a0 = pixels_per_step_rank * bytes_per_px / (kernel_ms * 1e-3) / 1e9
+        t0_, src0_ = preset_traffic(args.preset, args.workload, size, batch) if args.content == "noise" else (None, None)
+        result["roofline"] = {"bound": limiting_unit, "achieved": round(a0, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(a0 / HBM_PEAK_GBPS, 4), "traffic": t0_, "traffic_source": src0_,
+                              "kernel": pkg.kernel_name(codec, comps), "kernel_ms": round(kernel_ms, 4)}
+    # ---- watchdog: the contract's measurement is done; nothing below may cost the run its line.  Exceptions are caught leg by
+    # leg, but a collective that HANGS (the multi-rank paths have only ever run over gloo / one forced RCCL rank) would hold the
+    # line back until the launcher's own limit.  After --watchdog-seconds rank 0 prints what it has, every rank exits 0.
+    import threading
+    printed = threading.Lock()
+
+    def watchdog_fire():
+        if printed.acquire(False):
+            if rank == 0:
+                result["watchdog"] = "extra legs still running %.0f s after the headline measurement: line printed without the unfinished ones" \
+                    % args.watchdog_seconds
+                try:
+                    print(json.dumps(result, default=str), flush=True)
+                except Exception:
+                    print(json.dumps({k: v for k, v in result.items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                     "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "watchdog")}), flush=True)
+            os._exit(0)
+    watchdog = None
+    if args.watchdog_seconds > 0:
+        watchdog = threading.Timer(args.watchdog_seconds + (0.0 if rank == 0 else 5.0), watchdog_fire)
+        watchdog.daemon = True
+        watchdog.start()
+    # ---- timed region 2 (N > 1): encode -> RCCL gather of the compressed output on rank 0, overlapped
+    gather = None
+    probe = None
+    if distributed and not args.no_gather:
+        try:
+            probe = link_probe(ctx)
+        except Exception as e:
+            probe = None
+            print("bench.py: link probe failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+        try:
+            counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
+                else [(r * batch, (r + 1) * batch) for r in range(world)]
+            counts = [e - b for b, e in counts]
+            gather = gather_region(ctx, sharding, lambda slot: step(outs[slot]), outs, counts, args.steps, stream,
+                                   pixels_per_step_all, codec, probe)
+        except Exception as e:  # the encode-only line must survive a failing gather (it is reported, not hidden)
+            gather = {"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)}
+
     if gather is not None:
         result.update(gather)
     result["link_probe"] = probe
@@ -1377,11 +1408,22 @@ def main():
                 except Exception as e:
                     slabs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["slab"] = slabs
+    if not printed.acquire(False):  # the watchdog is printing: let it finish
+        time.sleep(30)
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        if args.watchdog_seconds > 0:  # the final barrier must not hang the exit either
+            bye = threading.Timer(60.0, lambda: os._exit(0))
+            bye.daemon = True
+            bye.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # a peer that already left (its watchdog): the line is out, leaving is all that remains
+            print("bench.py: rank %d: final barrier: %s: %s" % (rank, type(e).__name__, str(e)[:200]), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -962,6 +962,18 @@ def _run_bench(args, timeout=600):
     return json.loads(lines[-1])
 
 
+def test_bench_watchdog_prints_the_line_when_the_extra_legs_overrun(pkg):
+    """r05: after the contract's K timed steps nothing may cost the run its line.  With a 2 s watchdog the default command is
+    still inside its extra legs when it fires: ONE line, exit code 0, the headline fields and the roofline present, marked;
+    and over two gloo ranks every rank leaves (the launcher would otherwise report the survivors' time-outs)."""
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--watchdog-seconds", "2", "--precondition-seconds", "0"], timeout=300)
+    assert "watchdog" in d and d["value"] > 0 and d["n_gpus"] == 1 and d["roofline"]["frac"] > 0 and d["config"]["preset"] == "c2"
+    assert "slab" not in d  # (the last leg cannot have finished within 2 s)
+    d = _run_bench(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--watchdog-seconds", "2",
+                    "--precondition-seconds", "0"], timeout=300)
+    assert "watchdog" in d and d["n_gpus"] == 2 and d["value"] > 0
+
+
 def test_bench_bare_command_self_launches_ranks(pkg):
     """`python bench.py --gpus 2` outside torch.distributed.run starts its own two ranks and times both regions
     (encode only; encode -> gather on rank 0, overlapped).  On a 1-GPU box the ranks share the GPU over gloo with the
