@@ -265,7 +265,7 @@ def compress_host(compressor, fmt, buffer, height, width, *, padding_bytes_per_r
 
 def decode_device(codec, blocks, height, width, *, swap_rb=False, padding_bytes_per_row=0, n_images=1, stream=None):
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
-    comps = 4 if codec in (DXT5, PVRTC2) else 3
+    comps = 4 if codec in (DXT5, PVRTC2, PVRTC4) else 3
     per_out = height * (width * comps + padding_bytes_per_row)
     per_in = encoded_size(codec, height, width)
     out = torch.zeros((n_images, per_out), dtype=torch.uint8, device=blocks.device)

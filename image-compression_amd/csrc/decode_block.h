@@ -306,6 +306,79 @@ ICAMD_DEV void decode_pvrtc2_block_expanded(const uint32_t C[3][3][4], const uin
   });
 }
 
+// ---- PVRTC1 4 bpp decoder (r05): EXTENSION of an extension, PARITY UNPINNED (the reference has neither a 4 bpp format nor a
+// PVRTC decoder; BASELINE names the format).  The inverse of the 4 bpp encoder of pvrtc_block.h, the plain-C statement of the
+// same rules is oracle/ic_oracle.c pvrtc4_decode_image.  4 x 4 blocks, block centres at (2, 2): pixel (x, y) blends the low
+// resolution colours with weights (x + 2) & 3, (y + 2) & 3 out of 4 in both directions, toroidal; every pixel stores its own
+// 2-bit value: weights 0, 3, 5, 8 eighths of B (ApplyModulation, pvrtc.cc:120-144), or -- colour word bit 0 set, which the
+// encoder never writes -- PVRTC1's punch-through 0, 4, 4, 8 with alpha 0 for value 2.
+// C[r][c][v]: expanded colours of the 3 x 3 block neighbourhood; emit(y, row): the four pixels of pixel row y.
+// Same walk as the 2 bpp decoder at scale 256: V = 64 x vertical blend, P(px) = (4 - px) VL + px VR stepped by VR - VL.
+ICAMD_DEV uint32_t vblend4_pair(uint32_t py, uint32_t top, uint32_t bot) {
+  if (py == 0u) return top << 6;
+  if (py == 2u) return (top + bot) << 5;
+  return (py == 1u ? 3u * top + bot : top + 3u * bot) << 4;
+}
+template <typename Emit>
+ICAMD_DEV void decode_pvrtc4_block_rows(const uint32_t C[3][3][4], uint32_t data, bool punch, Emit emit) {
+  ICAMD_UNROLL
+  for (int y = 0; y < 4; ++y) {
+    const int r0b = y < 2 ? 0 : 1;                     // block rows (r0b, r0b + 1) bracket this pixel row
+    const uint32_t py = (uint32_t)((y + 2) & 3);
+    uint32_t V[3][4], row[4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c)
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) V[c][v] = vblend4_pair(py, C[r0b][c][v], C[r0b + 1][c][v]);
+    // the row's four 2-bit values on 16-bit lanes: pixels (0, 1) and (2, 3)
+    const uint32_t bits = bfe(data, 8 * y, 8), hb = bits >> 4;
+    const uint32_t S[2] = { (bits | bits << 14) & 0x00030003u, (hb | hb << 14) & 0x00030003u };
+    ICAMD_UNROLL
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t std_w = 3u * S[h] - ((S[h] >> 1) & 0x00010001u);                   // {0, 3, 5, 8}
+      const uint32_t pt_w = (((S[h] + 0x00010001u) >> 1) & 0x00030003u) << 2;            // {0, 4, 4, 8}
+      const uint32_t w32 = (punch ? pt_w : std_w) << 5, iw32 = 0x01000100u - w32;
+      const uint32_t hole = punch ? ((S[h] >> 1) & ~S[h] & 0x00010001u) : 0u;            // value 2 of a punch-through block
+      uint32_t P[4], D[4];
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        const uint32_t vl = V[h][v], vr = V[h + 1][v];
+        D[v] = vr - vl;
+        P[v] = h == 0 ? (vl + vr) << 1 : vl << 2;      // px = 2 / px = 0
+      }
+      ICAMD_UNROLL
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t a_rb = pk_lshr16(P[0], 8), a_ga = pk_lshr16(P[1], 8), b_rb = pk_lshr16(P[2], 8), b_ga = pk_lshr16(P[3], 8);
+        uint32_t rb, ga;
+        if (j) {
+          rb = pk_mad_u16_lane<1>(b_rb, w32, pk_mad_u16_lane<1>(a_rb, iw32, 0u));
+          ga = pk_mad_u16_lane<1>(b_ga, w32, pk_mad_u16_lane<1>(a_ga, iw32, 0u));
+        } else {
+          rb = pk_mad_u16_lane<0>(b_rb, w32, pk_mad_u16_lane<0>(a_rb, iw32, 0u));
+          ga = pk_mad_u16_lane<0>(b_ga, w32, pk_mad_u16_lane<0>(a_ga, iw32, 0u));
+        }
+        const uint32_t keep = ((hole >> (16 * j)) & 1u) ? 0x00ffffffu : 0xffffffffu;
+        row[2 * h + j] = perm(ga, rb, 0x07030501u) & keep;
+        if (j == 0) {
+          ICAMD_UNROLL
+          for (int v = 0; v < 4; ++v) P[v] += D[v];
+        }
+      }
+    }
+    emit(y, row);
+  }
+}
+// col[d] = colour word of the block at (dx, dy) = index 3 * (dy + 1) + dx + 1, data = the block's own modulation word
+ICAMD_DEV void decode_pvrtc4_block(uint32_t data, const uint32_t col[9], uint32_t px[16]) {
+  uint32_t C[3][3][4];
+  ICAMD_UNROLL
+  for (int i = 0; i < 9; ++i) pvrtc_expand_colors(col[i], C[i / 3][i % 3]);
+  decode_pvrtc4_block_rows(C, data, (col[4] & 1u) != 0u, [&](int y, const uint32_t row[4]) {
+    ICAMD_UNROLL
+    for (int x = 0; x < 4; ++x) px[4 * y + x] = row[x];
+  });
+}
+
 ICAMD_DEV void decode_pvrtc2_block(const uint32_t mod[9], const uint32_t col[9], uint32_t px[32]) {
   uint32_t C[3][3][4];  // [block row][block column][a_rb, a_ga, b_rb, b_ga]
   ICAMD_UNROLL

@@ -72,13 +72,16 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_etc1_decode_kernel
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
   if (k < P.total_blocks) decode_one<ICAMD_ETC1>(P, k);
 }
-// PVRTC1 2bpp (extension, see decode_block.h): one 8x4 block per lane, lanes in raster order of the block grid (a
-// wave writes 64 x 32 B = 2 KiB contiguous per pixel row); the nine block words come from their Z-order slots.
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_kernel(DecodeParams P) {
+}  // extern "C"
+
+// PVRTC1 2 bpp / 4 bpp (extensions, see decode_block.h): one block (8 x 4 / 4 x 4 pixels) per lane, lanes in raster order of the
+// block grid; the nine block words come from their Z-order slots.  Small textures (block grids below 32 x 8).
+template <int BPP>
+__device__ __forceinline__ void pvrtc_decode_generic(const DecodeParams &P) {
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
   if (k >= P.total_blocks) return;
   const uint32_t img = fastdiv(k, P.div_bpi), rem = k - img * P.blocks_per_image;
-  const uint32_t by = fastdiv(rem, P.div_cols), bx = rem - by * P.block_cols;  // block_cols = width / 8
+  const uint32_t by = fastdiv(rem, P.div_cols), bx = rem - by * P.block_cols;  // block_cols = width / 8 (2 bpp), / 4 (4 bpp)
   const U2 *blocks = reinterpret_cast<const U2 *>(P.blocks + (size_t)img * P.src_image_stride);
   uint32_t mod[9], col[9];
 #pragma unroll
@@ -90,27 +93,37 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_kern
       mod[3 * (dy + 1) + dx + 1] = w.x;
       col[3 * (dy + 1) + dx + 1] = w.y;
     }
-  uint32_t px[32];
-  decode_pvrtc2_block(mod, col, px);
-  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * P.row_stride + (size_t)bx * 32u;
+  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * P.row_stride + (size_t)bx * (BPP == 2 ? 32u : 16u);
+  if (BPP == 2) {
+    uint32_t px[32];
+    decode_pvrtc2_block(mod, col, px);
 #pragma unroll
-  for (int y = 0; y < 4; ++y) {  // (one 64-bit product above; the rows advance by additions)
-    U4 v0 = { px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3] };
-    U4 v1 = { px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7] };
-    *reinterpret_cast<U4 *>(dst) = v0;
-    *reinterpret_cast<U4 *>(dst + 16) = v1;
-    dst += P.row_stride;
+    for (int y = 0; y < 4; ++y) {  // (one 64-bit product above; the rows advance by additions)
+      U4 v0 = { px[8 * y], px[8 * y + 1], px[8 * y + 2], px[8 * y + 3] };
+      U4 v1 = { px[8 * y + 4], px[8 * y + 5], px[8 * y + 6], px[8 * y + 7] };
+      *reinterpret_cast<U4 *>(dst) = v0;
+      *reinterpret_cast<U4 *>(dst + 16) = v1;
+      dst += P.row_stride;
+    }
+  } else {
+    uint32_t px[16];
+    decode_pvrtc4_block(mod[4], col, px);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      U4 v0 = { px[4 * y], px[4 * y + 1], px[4 * y + 2], px[4 * y + 3] };
+      *reinterpret_cast<U4 *>(dst) = v0;
+      dst += P.row_stride;
+    }
   }
 }
-// The same for textures of 256^2 and more (block grids at least 32 x 64): one workgroup per TILE of 32 x 8 blocks.  Every
-// lane expands its own block's colour word once (the packed-field -> channel-pair expansion is a quarter of the per-block
-// work when each lane does it for all nine neighbours), the 84 blocks of the one-block ring around the tile are expanded
-// by the first 84 lanes, the pairs (16 B per block) meet in LDS, one barrier.  The modulation / mode words of the four
-// orthogonal neighbours still come from memory (L1 hits).
+// The same for block grids of at least 32 x 8: one workgroup per TILE of 32 x 8 blocks.  Every lane expands its own block's
+// colour word once (the packed-field -> channel-pair expansion is a quarter of the per-block work when each lane does it for all
+// nine neighbours), the 84 blocks of the one-block ring around the tile are expanded by the first 84 lanes, the pairs (16 B per
+// block) meet in LDS, one barrier.  The modulation / mode words of the four orthogonal neighbours (2 bpp only: its unstored
+// pixels look at them) still come from memory (L1 hits).
 constexpr uint32_t kPvrtcTileW = 32, kPvrtcTileH = 8;
-__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile_kernel(DecodeParams P) {
-  __shared__ U4 pairs[(kPvrtcTileH + 2) * (kPvrtcTileW + 2)];
-  __shared__ U4 turn[kThreadsPerWorkgroup / 64][128];
+template <int BPP>
+__device__ __forceinline__ void pvrtc_decode_tile(const DecodeParams &P, U4 *pairs, U4 (*turn)[128]) {
   const uint32_t log2_cols = 31u - (uint32_t)__builtin_clz(P.block_cols), log2_rows = 31u - (uint32_t)__builtin_clz(P.block_rows);
   const uint32_t tiles_x = P.block_cols >> 5, log2_tx = log2_cols - 5u, log2_tiles = log2_tx + log2_rows - 3u;
   const uint32_t img = blockIdx.x >> log2_tiles, tile = blockIdx.x & ((1u << log2_tiles) - 1u);
@@ -143,10 +156,12 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile
   }
   uint32_t mod[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, col[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   mod[4] = own.x; col[4] = own.y;
-  { const U2 w = blocks[sx | ((sy - 1u) & my)]; mod[1] = w.x; col[1] = w.y; }
-  { const U2 w = blocks[((sx - 2u) & mx) | sy]; mod[3] = w.x; col[3] = w.y; }
-  { const U2 w = blocks[(((sx | 0x55555555u) + 2u) & mx) | sy]; mod[5] = w.x; col[5] = w.y; }
-  { const U2 w = blocks[sx | (((sy | 0xaaaaaaaau) + 1u) & my)]; mod[7] = w.x; col[7] = w.y; }
+  if (BPP == 2) {
+    { const U2 w = blocks[sx | ((sy - 1u) & my)]; mod[1] = w.x; col[1] = w.y; }
+    { const U2 w = blocks[((sx - 2u) & mx) | sy]; mod[3] = w.x; col[3] = w.y; }
+    { const U2 w = blocks[(((sx | 0x55555555u) + 2u) & mx) | sy]; mod[5] = w.x; col[5] = w.y; }
+    { const U2 w = blocks[sx | (((sy | 0xaaaaaaaau) + 1u) & my)]; mod[7] = w.x; col[7] = w.y; }
+  }
   __syncthreads();
   uint32_t C[3][3][4];
 #pragma unroll
@@ -156,6 +171,17 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile
       const U4 v = pairs[(ly + (uint32_t)r) * (kPvrtcTileW + 2u) + lx + (uint32_t)c];
       C[r][c][0] = v.x; C[r][c][1] = v.y; C[r][c][2] = v.z; C[r][c][3] = v.w;
     }
+  const size_t row_stride = P.row_stride;
+  if (BPP == 4) {
+    // a lane's 16 bytes of a pixel row are one store: lanes 0-31 / 32-63 of a wave write 512 contiguous bytes (whole lines) of
+    // the two block rows they hold; non-temporal, row by row as the rows are finished
+    uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)(by * 4u) * row_stride + (size_t)bx * 16u;
+    decode_pvrtc4_block_rows(C, own.x, (own.y & 1u) != 0u, [&](int y, const uint32_t row[4]) {
+      store_stream16(dst, row[0], row[1], row[2], row[3]);
+      dst += row_stride;
+    });
+    return;
+  }
   // r05: a lane's 32 bytes of a pixel row leave as two 16-byte stores, and with the lanes' own data those would each fill every
   // other 16 bytes of the lines they touch (measured: this store pattern ALONE took 0.30 ms per 16 x 4096^2, the arithmetic 0.21).
   // Each wave therefore turns its row segment round in 2 KiB of LDS -- lane i writes pieces 2 i and 2 i + 1, reads pieces i and
@@ -163,8 +189,8 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile
   // tile, lanes 32-63 block row 2 w + 1), non-temporal: 0.166 ms for the same bytes.  No barrier: LDS is in order within a wave.
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   U4 *const mine = turn[wave];
-  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)((by0 + 2u * wave) * 4u) * P.row_stride + (size_t)bx0 * 32u + lane * 16u;
-  const size_t row_stride = P.row_stride, next_block_row = 4u * row_stride;
+  uint8_t *dst = P.pixels + (size_t)img * P.dst_image_stride + (size_t)((by0 + 2u * wave) * 4u) * row_stride + (size_t)bx0 * 32u + lane * 16u;
+  const size_t next_block_row = 4u * row_stride;
   decode_pvrtc2_block_rows(C, mod, col, [&](int y, const uint32_t row[8]) {  // (one 64-bit product above; the rows advance by additions)
     const U4 v0 = { row[0], row[1], row[2], row[3] }, v1 = { row[4], row[5], row[6], row[7] };
     mine[2u * lane] = v0;
@@ -176,6 +202,19 @@ __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile
     store_stream16(dst + next_block_row, b.x, b.y, b.z, b.w);
     dst += row_stride;
   });
+}
+
+extern "C" {
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_kernel(DecodeParams P) { pvrtc_decode_generic<2>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc4_decode_kernel(DecodeParams P) { pvrtc_decode_generic<4>(P); }
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc2_decode_tile_kernel(DecodeParams P) {
+  __shared__ U4 pairs[(kPvrtcTileH + 2) * (kPvrtcTileW + 2)];
+  __shared__ U4 turn[kThreadsPerWorkgroup / 64][128];
+  pvrtc_decode_tile<2>(P, pairs, turn);
+}
+__global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_pvrtc4_decode_tile_kernel(DecodeParams P) {
+  __shared__ U4 pairs[(kPvrtcTileH + 2) * (kPvrtcTileW + 2)];
+  pvrtc_decode_tile<4>(P, pairs, nullptr);
 }
 }  // extern "C"
 
@@ -190,6 +229,10 @@ hipError_t launch_decode(int codec, const DecodeParams &P, hipStream_t stream) {
            (P.block_cols & (P.block_cols - 1u)) == 0u && (P.block_rows & (P.block_rows - 1u)) == 0u)
     hipLaunchKernelGGL(icamd_pvrtc2_decode_tile_kernel, grid, block, 0, stream, P);  // whole tiles: total_blocks / 256 workgroups
   else if (codec == ICAMD_PVRTC2) hipLaunchKernelGGL(icamd_pvrtc2_decode_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_PVRTC4 && P.block_cols >= kPvrtcTileW && P.block_rows >= kPvrtcTileH &&
+           (P.block_cols & (P.block_cols - 1u)) == 0u && (P.block_rows & (P.block_rows - 1u)) == 0u)
+    hipLaunchKernelGGL(icamd_pvrtc4_decode_tile_kernel, grid, block, 0, stream, P);
+  else if (codec == ICAMD_PVRTC4) hipLaunchKernelGGL(icamd_pvrtc4_decode_kernel, grid, block, 0, stream, P);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

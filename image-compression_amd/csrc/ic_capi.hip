@@ -569,7 +569,7 @@ static int decode_launch(int codec, int swap_rb, uint32_t height, uint32_t width
   P.height = height;
   P.width = width;
   P.block_rows = num_blocks4(height);
-  P.block_cols = codec == ICAMD_PVRTC2 ? width / 8u : num_blocks4(width);  // PVRTC: 8x4-pixel blocks
+  P.block_cols = codec == ICAMD_PVRTC2 ? width / 8u : num_blocks4(width);  // PVRTC 2 bpp: 8x4-pixel blocks
   P.row_stride = row_stride;
   P.blocks_per_image = P.block_rows * P.block_cols;
   P.total_blocks = P.blocks_per_image * n_images;
@@ -584,18 +584,19 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
                         uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
                         const void *d_blocks, void *d_pixels, void *hip_stream) {
   if (!d_blocks || !d_pixels || height == 0 || width == 0) return ICAMD_FALSE;
-  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1 && codec != ICAMD_PVRTC2) return ICAMD_FALSE;
+  if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1 && codec != ICAMD_PVRTC2 && codec != ICAMD_PVRTC4)
+    return ICAMD_FALSE;
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const uint8_t *blocks = static_cast<const uint8_t *>(d_blocks);
   uint8_t *pixels = static_cast<uint8_t *>(d_pixels);
-  if (codec == ICAMD_PVRTC2) {
-    // EXTENSION (the reference's PvrtcCompressor::Decompress returns false, pvrtc.cc:669-672): the sizes
-    // PvrtcCompressor::Compress accepts (pvrtc.cc:636-650), RGBA8 out, no row padding, one launch per <= 2^30 blocks
+  if (codec == ICAMD_PVRTC2 || codec == ICAMD_PVRTC4) {
+    // EXTENSION (the reference's PvrtcCompressor::Decompress returns false, pvrtc.cc:669-672; 4 bpp: no such format there at
+    // all): the sizes PvrtcCompressor::Compress accepts (pvrtc.cc:636-650), RGBA8 out, no row padding, one launch per <= 2^30 blocks
     if (!is_pow2(width) || width != height || width < 8 || padding_bytes_per_row != 0) return ICAMD_FALSE;
-    const uint64_t pv_bpi = (uint64_t)(width / 8) * (height / 4);
+    const uint64_t pv_bpi = (uint64_t)(width / (codec == ICAMD_PVRTC2 ? 8 : 4)) * (height / 4);
     if (pv_bpi >= (1ull << 31)) return fail(ICAMD_ERR_ARG, "PVRTC texture too large to decode");
     const uint64_t per_launch = std::max<uint64_t>(1, ((1ull << 31) - 1) / pv_bpi);
     for (uint64_t first = 0; first < n_images; first += per_launch) {

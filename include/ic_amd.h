@@ -157,11 +157,14 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
 
 /* ---- "next" row 8f.1: block decoders on device (Compressor::Decompress, compressor.h:85-86;
  * helper.h:218-262, dxtc.cc:167-267, etc.cc:198-289).  Writes height rows of
- * width*comps + padding_bytes_per_row bytes (comps = 4 for DXT5 and PVRTC2, else 3).
+ * width*comps + padding_bytes_per_row bytes (comps = 4 for DXT5, PVRTC2 and PVRTC4, else 3).
  * codec ICAMD_PVRTC2 is an EXTENSION with PARITY UNPINNED: the reference has no PVRTC decoder
  * (PvrtcCompressor::Decompress returns false, pvrtc_compressor.cc:669-672, and so does icamd_decompress); this one is
  * written from the encoder's own rules (up-sampling pvrtc.cc:173-237, modulation :111-135, block layout :356-496,
- * Z order :80-86) and needs square power-of-two sizes and padding_bytes_per_row == 0. */
+ * Z order :80-86) and needs square power-of-two sizes and padding_bytes_per_row == 0.  codec ICAMD_PVRTC4 (r05) is the
+ * decoder of the 4 bpp extension encoder, under the same conditions and as unpinned as that: 4 x 4 blocks, every pixel its
+ * own 2-bit value (weights 0, 3, 5, 8; a block with colour-word bit 0 set -- the encoder never writes one -- takes PVRTC1's
+ * punch-through weights 0, 4, 4, 8 with alpha 0 for value 2). */
 int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
                         uint32_t padding_bytes_per_row, uint32_t n_images,
                         size_t src_image_stride_bytes, size_t dst_image_stride_bytes,

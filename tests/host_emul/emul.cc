@@ -74,8 +74,24 @@ static int emul_decode_pvrtc2(uint32_t n, const uint8_t *blocks, uint8_t *out) {
   return 1;
 }
 
+static int emul_decode_pvrtc4(uint32_t n, const uint8_t *blocks, uint8_t *out) {
+  const uint32_t bw = n / 4, bh = n / 4;
+  const uint32_t *words = reinterpret_cast<const uint32_t *>(blocks);
+  for (uint32_t by = 0; by < bh; ++by)
+    for (uint32_t bx = 0; bx < bw; ++bx) {
+      uint32_t col[9], px[16];
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx)
+          col[3 * (dy + 1) + dx + 1] = words[2 * pvrtc_z_index((bx + bw + dx) % bw, (by + bh + dy) % bh) + 1];
+      decode_pvrtc4_block(words[2 * pvrtc_z_index(bx, by)], col, px);
+      for (int i = 0; i < 16; ++i) memcpy(out + 4 * ((size_t)(by * 4 + i / 4) * n + bx * 4 + i % 4), &px[i], 4);
+    }
+  return 1;
+}
+
 extern "C" int emul_decode(int codec, int swap, uint32_t h, uint32_t w, uint32_t pad, const uint8_t *blocks, uint8_t *out) {
   if (codec == 3) return emul_decode_pvrtc2(w, blocks, out);
+  if (codec == 4) return emul_decode_pvrtc4(w, blocks, out);
   const int comps = codec == 1 ? 4 : 3;
   const uint32_t rows = (h + 3) / 4, cols = (w + 3) / 4;
   const size_t stride = (size_t)w * comps + pad;

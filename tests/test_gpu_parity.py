@@ -558,6 +558,38 @@ def test_pvrtc_decoder_matches_oracle(pkg):
     assert pkg.pvrtc_decompress_host(small, 32) is None
 
 
+def test_pvrtc4_decoder_matches_oracle(pkg):
+    """r05: PVRTC 4 bpp decoder on the device (the decoder of the 4 bpp extension encoder; parity unpinned twice over) against
+    the oracle's statement of the same rules: the device encoder's output, random block words (half of them punch-through
+    blocks, which the encoder never writes), batches through both kernels (block grids below / from 32 x 8), 4096^2, and
+    the round trip encode -> decode on the device against encode -> decode in the oracle."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(37))
+    for n in (8, 16, 32, 64, 128, 256, 512):  # (128^2 is the first size of the tiled kernel: one tile wide, its ring wraps onto itself)
+        cases = [T.oracle_encode(T.PVRTC4, T.GENERATORS[gen](n, n, 4, index=n + 2), n, n, 4) for gen in ("noise", "mixed", "flat")]
+        cases.append(rng.integers(0, 256, size=n * n // 2, dtype=np.uint8).tobytes())
+        for blocks in cases:
+            dec = pkg.decode_device(T.PVRTC4, _dev(np.frombuffer(blocks, np.uint8)), n, n)
+            assert _host(dec) == T.oracle_decode(T.PVRTC4, blocks, n, n).tobytes(), n
+    for n, k in ((64, 5), (128, 3), (1024, 2)):
+        words = rng.integers(0, 256, size=(k, n * n // 2), dtype=np.uint8)
+        dec = pkg.decode_device(T.PVRTC4, _dev(words), n, n, n_images=k)
+        torch.cuda.synchronize()
+        for i in range(k):
+            assert dec[i].cpu().numpy().tobytes() == T.oracle_decode(T.PVRTC4, words[i].tobytes(), n, n).tobytes(), (n, i)
+    n = 4096
+    img = T.s_smooth(n, n, 4, index=13)
+    enc = pkg.encode_device(T.PVRTC4, _dev(img), n, n, 4)
+    dec = pkg.decode_device(T.PVRTC4, enc.reshape(-1), n, n)
+    want = T.oracle_decode(T.PVRTC4, _host(enc), n, n)
+    assert hashlib.sha256(_host(dec)).hexdigest() == hashlib.sha256(want.tobytes()).hexdigest()
+    mse = float(((want.reshape(n, n, 4).astype(np.float64) - img.astype(np.float64)) ** 2).mean())
+    assert 10.0 * np.log10(255.0 * 255.0 / mse) > 18.0  # (s_smooth carries 5 bits of noise and a random alpha: 20.6 dB)
+    assert pkg.decode_device(T.PVRTC4, enc.reshape(-1), 4096, 2048) is None
+    assert pkg.decode_device(T.PVRTC4, enc.reshape(-1), 24, 24) is None
+    assert pkg.decode_device(T.PVRTC4, enc.reshape(-1), 64, 64, padding_bytes_per_row=4) is None
+
+
 def test_pvrtc_call_sequences_host_api(pkg):
     # Regression: results must not depend on what ran before in the process (workspace / staging reuse).
     # A 128^2 image spans two workgroups of each PVRTC kernel, 64^2 and 8^2 only one.

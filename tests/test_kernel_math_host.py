@@ -372,6 +372,25 @@ def test_pvrtc_decode_math_matches_oracle(emul):
             assert np.array_equal(out, want), n
 
 
+def test_pvrtc4_decode_math_matches_oracle(emul):
+    """PVRTC 4 bpp decoder (r05; extension of an extension, parity unpinned): device block math vs the oracle's plain-C
+    statement of the same rules, on the 4 bpp encoder's output and on random block words -- half of which carry the
+    punch-through flag the encoder never writes (weights 0, 4, 4, 8, alpha 0 for value 2)."""
+    emul.emul_decode.restype = ctypes.c_int
+    emul.emul_decode.argtypes = [T.ci, T.ci, T.u32, T.u32, T.u32, T.vp, T.vp]
+    g = np.random.Generator(np.random.PCG64(31))
+    for n in (8, 16, 64, 128):
+        cases = [np.frombuffer(T.oracle_encode(T.PVRTC4, T.GENERATORS[gen](n, n, 4, index=n), n, n, 4), np.uint8)
+                 for gen in ("noise", "smooth", "flat", "mixed")]
+        cases += [g.integers(0, 256, size=n * n // 2, dtype=np.uint8) for _ in range(3)]
+        for blocks in cases:
+            want = T.oracle_decode(T.PVRTC4, blocks.tobytes(), n, n)
+            out = np.zeros(n * n * 4, np.uint8)
+            b = np.ascontiguousarray(blocks)
+            assert emul.emul_decode(T.PVRTC4, 0, n, n, 0, b.ctypes.data, out.ctypes.data)
+            assert np.array_equal(out, want), n
+
+
 def test_pvrtc_decode_properties():
     """What ties the (reference-less) PVRTC decoder to the ENCODER's model: a solid texture decodes to the encoder's
     channel-reduced colour (pvrtc.cc:337-349); in a 1BPP block the block-centre pixels (x % 8 == 4, y % 4 == 2), where
