@@ -180,5 +180,19 @@ t = timeit(dec_pvrtc)
 print("decode pvrtc %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s (extension: the reference has no PVRTC decoder)" % (
     batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
     parity("decode pvrtc", out[0], T.oracle_decode(3, blocks[0].cpu().numpy().tobytes(), n, n).tobytes())))
+# PVRTC 4 bpp decoder (r05: the decoder of the 4 bpp extension encoder; parity unpinned like it)
+del blocks
+src = torch.randint(0, 256, (batch, n, n, 4), dtype=torch.uint8, device=dev, generator=g)
+blocks = pkg.encode_device(4, src, n, n, 4, n_images=batch)
+torch.cuda.synchronize()
+del src
+def dec_pvrtc4():
+    rc = L.icamd_decode_device(4, 0, n, n, 0, batch, blocks.shape[1], out.shape[1], ctypes.c_void_p(blocks.data_ptr()),
+                               ctypes.c_void_p(out.data_ptr()), sh)
+    assert rc == 0
+t = timeit(dec_pvrtc4)
+print("decode pvrtc4 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s (extension of an extension: no reference for the format)" % (
+    batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
+    parity("decode pvrtc4", out[0], T.oracle_decode(4, blocks[0].cpu().numpy().tobytes(), n, n).tobytes())))
 print("next rows: %s" % ("ALL LEGS bit-exact vs oracle at the timed shape" if not BAD else "MISMATCH in: " + ", ".join(BAD)))
 sys.exit(1 if BAD else 0)
