@@ -1094,6 +1094,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_distributed(args)
+    # (the host driver only supports dmabuf IPC: without this RCCL's peer mappings fail with hipIpcGetMemHandle: invalid argument;
+    # exported already by the boxes this runs on -- a launcher that scrubbed the environment must not cost the N > 1 run)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import ic_amd_loader
