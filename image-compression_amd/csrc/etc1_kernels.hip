@@ -1,6 +1,7 @@
 // etc1_kernels.hip -- ETC1 encode kernels for gfx950 (MI355X); see etc1_block.h for the math.
 // Same one-block-per-lane tile mapping as dxt_kernels.hip, with 16 x 16-block tiles.  VALU-bound (3.5-4.3 k integer instructions per block at
 // kSmallerError, 98 % issue utilisation); the 3.5 / 4.5 B/px of HBM traffic are a small fraction of the roofline.
+#include <cstdlib>
 #include "etc1_block.h"
 #include "ic_launch.h"
 #include "ic_amd.h"
@@ -192,6 +193,50 @@ __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
   store_stream8(dst_base + (tag & ~7u), c.lo, c.hi);
 }
 
+// ---- kSmallerError for SMALL launches (r05): four lanes per block.  A 256^2 texture is 4 096 blocks = 64 waves of ~2 600
+// dependent instructions on 64 of the chip's 1 024 SIMDs: latency, not throughput.  With the four searches of a block on four
+// lanes (etc1_block.h encode_etc1_block_quad, the form the Pad border uses) it is 256 waves of ~900.  The tile stays 16 x 16
+// blocks; its 1 024 lanes are 16 one-wave workgroups of 16 blocks (one row of the tile) x 4 lanes.  One-colour blocks keep
+// their own form (lane 0 of the quad writes it).  launch_etc1 takes this kernel while the launch has at most
+// kEtc1QuadMaxBlocks (36 864) blocks -- above that every SIMD has a wave of the one-lane form anyway, which needs fewer instructions
+// in total.  Same bytes: tests/test_gpu_parity.py runs both forms on the same inputs.
+template <int COMPS>
+__device__ __forceinline__ void etc1_encode_quad(const GridParams &P) {
+  TileCoord t;
+  const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
+  const uint32_t vb = (threadIdx.x >> 2) + 16u * (blockIdx.x & 15u), q = threadIdx.x & 3u;  // block of the tile, lane of the quad
+  t.lx = vb & (cols - 1u);
+  t.ly = vb >> P.log2_tile_cols;
+  t.bcol0 = (blockIdx.x >> 4) * cols;
+  t.brow0 = (blockIdx.y + P.tile_row0) * rows;
+  t.bcol = t.bcol0 + t.lx;
+  t.brow = t.brow0 + t.ly;
+  t.img = blockIdx.z;
+  t.full = t.bcol0 + cols <= P.block_cols && t.brow0 + rows <= P.block_rows;
+  t.interior = (t.bcol0 + cols) * 4u <= P.width && (t.brow0 + rows) * 4u <= P.height;
+  t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
+  if (!t.valid) return;  // (whole quads)
+  uint32_t px[16];
+  load_tile_block<COMPS>(P, t, px);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int p = 1; p < 16; ++p) diff |= px[p] ^ px[0];
+  Out8 c;
+  bool writes;
+  if ((diff & 0x00ffffffu) == 0u) {  // one colour (per quad): the form of its own, no search
+    c = encode_etc1_constant_block(px[0], 2u);
+    writes = q == 0u;
+  } else {
+    c = encode_etc1_block_quad(px, q, &writes);
+  }
+  if (writes) store_stream8(tile_dst<8>(P, t), c.lo, c.hi);
+}
+
+extern "C" {
+__global__ void __launch_bounds__(64) icamd_etc1_rgb888_quad_kernel(GridParams P) { etc1_encode_quad<3>(P); }
+__global__ void __launch_bounds__(64) icamd_etc1_rgba8_quad_kernel(GridParams P) { etc1_encode_quad<4>(P); }
+}
+
 extern "C" {
 
 // (amdgpu_waves_per_eu(4): the search must fit 128 VGPRs -- left alone the allocator takes 139 for kSmallerError with the
@@ -224,6 +269,10 @@ extern "C" __attribute__((visibility("default"))) int icamd_debug_etc1_stats(uns
 }
 #endif
 
+// measured (profiles/r05_ab_etc1_small.log): one call alone 17.1 -> 12.2 us at 256^2, 17.4 -> 12.8 at 512^2, 17.9 -> 16.5 at 768^2,
+// 18.3 -> 19.0 at 1024^2 (there every SIMD has a wave of the one-lane form, which needs fewer instructions in total)
+constexpr uint32_t kEtc1QuadMaxBlocks = 36864;  // one 768^2 texture, two 512^2, nine 256^2
+
 const char *etc1_kernel_name(int comps) { return comps == 4 ? "icamd_etc1_rgba8_kernel" : "icamd_etc1_rgb888_kernel"; }
 
 hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
@@ -241,7 +290,18 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   static const Kernel kernels[2][4] = {
     { icamd_etc1_rgb888_split_h_kernel, icamd_etc1_rgb888_split_v_kernel, icamd_etc1_rgb888_kernel, icamd_etc1_rgb888_heuristic_kernel },
     { icamd_etc1_rgba8_split_h_kernel, icamd_etc1_rgba8_split_v_kernel, icamd_etc1_rgba8_kernel, icamd_etc1_rgba8_heuristic_kernel } };
-  const Kernel k = kernels[comps == 4 ? 1 : 0][P.etc_strategy < 4u ? P.etc_strategy : 2u];
+  const uint32_t strategy = P.etc_strategy < 4u ? P.etc_strategy : 2u;
+  // r05: small kSmallerError launches take four lanes per block (etc1_encode_quad); ICAMD_ETC1_QUAD_MAX_BLOCKS overrides the
+  // threshold (0 = never) for the A/B
+  static const uint64_t quad_max = [] {
+    const char *e = getenv("ICAMD_ETC1_QUAD_MAX_BLOCKS");
+    return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)kEtc1QuadMaxBlocks;
+  }();
+  if (strategy == 2u && (uint64_t)P.block_rows * P.block_cols * P.n_images <= quad_max && P.block_cols < (1u << 20)) {
+    const Kernel q = comps == 4 ? icamd_etc1_rgba8_quad_kernel : icamd_etc1_rgb888_quad_kernel;
+    return launch_tiled(q, q, P, stream, 4u, 1, true, 4u);
+  }
+  const Kernel k = kernels[comps == 4 ? 1 : 0][strategy];
   return launch_tiled(k, k, P, stream, cap, 1, etc1_wave_workgroups(P.etc_strategy < 4u ? (int)P.etc_strategy : 2));
 }
 

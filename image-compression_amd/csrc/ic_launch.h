@@ -26,7 +26,7 @@ template <typename Kernel>
 // wave_workgroups: every wave of a tile is launched as its own 64-lane workgroup (grid.x = 4 x column tiles; the kernel
 // undoes it: etc1_locate_tile)
 hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, hipStream_t stream,
-                        uint32_t max_log2_cols = 8, uint32_t wide_rows = 1, bool wave_workgroups = false) {
+                        uint32_t max_log2_cols = 8, uint32_t wide_rows = 1, bool wave_workgroups = false, uint32_t lanes_per_block = 1) {
   if (P.n_images == 0 || P.block_rows == 0 || P.block_cols == 0) return hipSuccess;
   P.log2_tile_cols = tile_log2_cols(P.block_cols);
   if (P.log2_tile_cols > max_log2_cols) P.log2_tile_cols = max_log2_cols;
@@ -48,7 +48,9 @@ hipError_t launch_tiled(Kernel wide_kernel, Kernel narrow_kernel, GridParams P, 
       Q.dst = P.dst + (uint64_t)first * P.dst_image_stride;
       Q.tile_row0 = row0;
       const uint32_t gyc = gy - row0 < 65535u ? gy - row0 : 65535u;
-      hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel, dim3(wave_workgroups ? gx * 4u : gx, gyc, count),
+      // (lanes_per_block = 4: the tile's 256 blocks are 16 one-wave workgroups of 16 blocks x 4 lanes, etc1_locate_tile_quad)
+      hipLaunchKernelGGL(P.log2_tile_cols == 8 ? wide_kernel : narrow_kernel,
+                         dim3(wave_workgroups ? gx * 4u * lanes_per_block : gx, gyc, count),
                          dim3(wave_workgroups ? 64 : kThreadsPerWorkgroup), 0, stream, Q);
     }
   }

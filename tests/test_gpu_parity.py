@@ -657,6 +657,47 @@ def test_blockops_match_oracle(pkg):
     assert pkg.transcode_dxt1_to_etc1_host(enc) == T.oracle_transcode(enc)
 
 
+def test_etc1_small_launches_four_lanes_per_block_match_oracle(pkg):
+    """r05: kSmallerError launches of at most 36 864 blocks run four lanes per block (icamd_etc1_rgb888/rgba8_quad_kernel).  The
+    same inputs through that form (threshold forced up), through the one-lane form (threshold 0) and with the shipped
+    threshold -- ragged sizes, RGBA, a batch, one-colour blocks inside searching waves, row padding -- all against the oracle;
+    the threshold is read once per process, hence the child processes."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import ic_amd_loader, ic_testlib as T
+pkg = ic_amd_loader.load_package()
+bad = 0
+for (h, w, comps, gen) in [(256, 256, 3, "noise"), (256, 256, 4, "mixed"), (61, 59, 3, "mixed"), (5, 3, 3, "noise"), (1, 1, 3, "flat"),
+                           (128, 512, 3, "flat"), (512, 512, 3, "smooth"), (64, 1024, 4, "smooth")]:
+    img = T.GENERATORS[gen](h, w, comps, index=h + w)
+    out = pkg.encode_device(T.ETC1, torch.from_numpy(img).cuda(), h, w, comps)
+    torch.cuda.synchronize()
+    bad += out.cpu().numpy().tobytes() != T.oracle_encode(T.ETC1, img, h, w, comps)
+imgs = np.stack([T.s_mixed(128, 128, 3, index=50 + i) for i in range(5)])
+imgs[2, 32:64, :, :] = imgs[2, 0, 0, :]          # a band of one-colour blocks inside searching waves
+out = pkg.encode_device(T.ETC1, torch.from_numpy(imgs).cuda(), 128, 128, 3, n_images=5)
+torch.cuda.synchronize()
+for i in range(5):
+    bad += out[i].cpu().numpy().tobytes() != T.oracle_encode(T.ETC1, imgs[i], 128, 128, 3)
+pad = T.with_row_padding(T.s_noise(37, 41, 3, index=4), 7)
+got = pkg.compress_host(T.ETC, T.RGB, pad, 37, 41, padding_bytes_per_row=7)
+bad += got != T.oracle_compress(T.ETC, T.RGB, pad, 37, 41, 7)
+print("KERNEL", pkg.lib().icamd_version().decode())
+print("BAD", bad)
+""" % (T.ROOT, T.ROOT)
+    for setting in ("0", str(1 << 40), None):
+        env = dict(os.environ)
+        env.pop("ICAMD_ETC1_QUAD_MAX_BLOCKS", None)
+        if setting is not None:
+            env["ICAMD_ETC1_QUAD_MAX_BLOCKS"] = setting
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("BAD 0"), (setting, r.stdout[-300:], r.stderr[-800:])
+
+
 def test_etc1_pad_quad_lanes_and_one_lane_forms_match_oracle(pkg):
     """r05: the kSmallerError Pad runs as ONE launch whose first workgroups are the pad blocks with FOUR lanes each
     (encode_etc1_block_quad).  Arbitrary ETC1 block words (saturated bases, clamping codewords, partition ties), batched
