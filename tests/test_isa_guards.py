@@ -147,6 +147,12 @@ def test_etc1_encode_kernels_keep_four_waves_per_simd(tmp_path):
             assert meta["vgprs"] <= 128, (name, meta)  # 512 VGPRs per SIMD lane / 4 waves
             assert meta["scratch"] <= max_scratch, (name, meta)
             assert meta["lds"] == 0, (name, meta)
+        # r05: the four-lanes-per-block form of small launches -- a latency play, it must stay light (8 waves per SIMD) and
+        # keep its quad exchange
+        name = "icamd_etc1_%s_quad_kernel" % src
+        meta = _kernel_meta(text, name)
+        assert meta["vgprs"] <= 64 and meta["scratch"] == 0 and meta["lds"] == 0, (name, meta)
+        assert sum("quad_perm" in l for l in _body(text, name)) >= 3, name
 
 
 @pytest.mark.parametrize("flags", [[], ["-DICAMD_PVRTC_SCALAR_ROW"]])
