@@ -96,9 +96,13 @@ __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
 
 // STRATEGY: the ETC1 re-encode strategy as a compile-time constant (one kernel per strategy, like the encoders: the
 // kSmallerError search is not carried along by a kHeuristic downsample and vice versa); ignored for DXT.
-template <int CODEC, int STRATEGY>
+// QUAD (ETC1 kSmallerError, small grids -- the low levels of a mip chain): work item k = 4 * output block + quad lane; the four
+// lanes build the same sixteen pixels and split the re-encode's searches (etc1_block.h encode_etc1_block_quad).
+template <int CODEC, int STRATEGY, bool QUAD = false>
 __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t k, BlockStash &stash) {
   constexpr int W = kWords(CODEC);
+  const uint32_t quad_lane = QUAD ? (k & 3u) : 0u;
+  if (QUAD) k >>= 2;
   // image of a batched launch, then (r, c) inside its output grid
   uint32_t img = 0, kk = k;
   if (P.n_images > 1) {
@@ -169,9 +173,15 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
 #pragma unroll
       for (int j = 0; j < 2; ++j) store_downsampled(tmp, 2 * i, 2 * j, px);
   }
+  uint8_t *dst = P.dst + (size_t)img * P.dst_image_stride + (size_t)kk * (W * 4);
+  if (QUAD) {
+    bool writes = false;
+    const Out8 o = encode_etc1_block_quad(px, quad_lane, &writes);
+    if (writes) store_stream8(dst, o.lo, o.hi);
+    return;
+  }
   uint32_t out[4];
   encode_any<CODEC>(px, CODEC == ICAMD_ETC1 ? (uint32_t)STRATEGY : 0u, stash, out);
-  uint8_t *dst = P.dst + (size_t)img * P.dst_image_stride + (size_t)kk * (W * 4);
   if (W == 4) store_stream16(dst, out[0], out[1], out[2], out[3]);
   else store_stream8(dst, out[0], out[1]);
 }
@@ -224,6 +234,15 @@ ICAMD_DOWNSAMPLE_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_split_v, ICAMD_ETC1, 1)
 ICAMD_DOWNSAMPLE_KERNEL(etc1, ICAMD_ETC1, 2)  // kSmallerError (and every value the reference's default: label maps to it)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
+// kSmallerError on grids of at most kDownsampleQuadMaxBlocks output blocks (r05): four lanes per output block.  A 512^2 level is
+// 4 096 output blocks = 64 waves of ~3 000 dependent instructions on 64 of 1 024 SIMDs; the quad form makes it 256 waves of ~1 500.
+constexpr uint32_t kDownsampleQuadMaxBlocks = 36864;
+extern "C" __global__ void __launch_bounds__(64) icamd_downsample_etc1_quad_kernel(BlockOpParams P) {
+  BlockStash stash;
+  stash.base = nullptr;  // (only the DXT colour encoder parks pixels)
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if ((k >> 2) < P.total_out) downsample_one<ICAMD_ETC1, 2, true>(P, k, stash);
+}
 
 extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup) icamd_dxt1_to_etc1_kernel(uint2 *blocks, uint32_t n) {
   const uint32_t k = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x;
@@ -285,6 +304,8 @@ hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stre
     if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_downsample_etc1_split_h_kernel, egrid, eblock, 0, stream, P);
     else if (P.etc_strategy == 1u) hipLaunchKernelGGL(icamd_downsample_etc1_split_v_kernel, egrid, eblock, 0, stream, P);
     else if (P.etc_strategy == 3u) hipLaunchKernelGGL(icamd_downsample_etc1_heuristic_kernel, egrid, eblock, 0, stream, P);
+    else if (P.total_out <= kDownsampleQuadMaxBlocks && pad_border_quad())  // (the same A/B switch as the Pad border: ICAMD_PAD_BORDER_QUAD=0)
+      hipLaunchKernelGGL(icamd_downsample_etc1_quad_kernel, dim3((P.total_out * 4u + 63u) / 64u), dim3(64), 0, stream, P);
     else hipLaunchKernelGGL(icamd_downsample_etc1_kernel, egrid, eblock, 0, stream, P);
   } else return hipErrorInvalidValue;
   return hipGetLastError();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Long seeded random parity soak on the GPU box: the GPU tier's test_random_soak_matches_oracle with more seeds.
-usage: python scripts/parity_soak.py [n_seeds]   (each seed = 400 block-codec cases + 60 PVRTC cases)"""
+usage: python scripts/parity_soak.py [n_seeds [seed_base]]   (each seed = 400 block-codec cases + 60 PVRTC cases; seed_base 0 =
+the cases every round repeats, anything else = fresh ones)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,9 +9,10 @@ import numpy as np, torch
 import ic_amd_loader, ic_testlib as T
 pkg = ic_amd_loader.load_package()
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+seed_base = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 t0 = time.time(); cases = 0; bad = 0
 for seed in range(n_seeds):
-    for (codec, comps, swap, strategy, h, w, pad, img) in T.soak_cases(0xA000 + seed, 400, 60, max_h=260, max_w=400, max_log2_pvrtc=6):
+    for (codec, comps, swap, strategy, h, w, pad, img) in T.soak_cases(0xA000 + seed_base + seed, 400, 60, max_h=260, max_w=400, max_log2_pvrtc=6):
         src = T.with_row_padding(img, pad)
         stride = w * comps + pad
         want = T.oracle_encode(codec, src, h, w, comps, swap, strategy, stride=stride)
@@ -24,7 +26,7 @@ for seed in range(n_seeds):
 print("encode soak: %d cases, %d mismatches, %.1f s" % (cases, bad, time.time() - t0))
 
 # compressed-domain operations and decoders ("next" rows): random geometry, random content, all strategies
-rng = np.random.Generator(np.random.PCG64(0xB10C))
+rng = np.random.Generator(np.random.PCG64(0xB10C + seed_base))
 ops = 0
 for it in range(60 * n_seeds):
     compressor, fmt, strategy = [(T.DXTC, T.RGB, 2), (T.DXTC, T.BGR, 2), (T.DXTC, T.RGBA, 2), (T.DXTC, T.BGRA, 2),

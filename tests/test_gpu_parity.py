@@ -728,6 +728,13 @@ out = pkg.pad_batch_device(T.ETC, T.RGB, src, h, w, ph, pw, etc_strategy=2)  # (
 torch.cuda.synchronize()
 for i, q in enumerate(grids):
     bad += out[i].cpu().numpy().tobytes() != T.oracle_pad(T.ETC, T.RGB, q.tobytes(), h, w, ph, pw, 2)
+# the same switch covers Downsample's small grids (icamd_downsample_etc1_quad_kernel): a mip chain 256 -> 4 of arbitrary words,
+# every level against the oracle's
+cur, s = g.integers(0, 256, size=(256 // 4) ** 2 * 8, dtype=np.uint8).tobytes(), 256
+while s > 4:
+    nxt = pkg.downsample_host(T.ETC, T.RGB, cur, s, s, 2)
+    bad += nxt != T.oracle_downsample(T.ETC, T.RGB, cur, s, s, 2)
+    cur, s = T.oracle_downsample(T.ETC, T.RGB, cur, s, s, 2), s // 2
 print("BAD", bad)
 """ % (T.ROOT, T.ROOT)
     for quad in ("1", "0"):
