@@ -94,6 +94,11 @@ def parse_args(argv=None):
     ap.add_argument("--content", default="noise", choices=["noise", "smooth", "flat"])
     ap.add_argument("--etc-strategy", type=int, default=None)
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the encode->gather region")
+    ap.add_argument("--no-next-rows", action="store_true",
+                    help="default line, N = 1: skip the `next_rows` legs (decoders, Downsample, DXT1->ETC1 transcode of 16 x 4096^2)")
+    ap.add_argument("--gather-impl", choices=["c", "torch"], default="c",
+                    help="N > 1, nccl backend: the gather legs use the library's own collective (icamd_gather_blocks_rccl on its own "
+                         "ncclComm_t, default) or torch.distributed's dist.gather / isend-irecv")
     ap.add_argument("--shard", default="textures", choices=["textures", "slab"],
                     help="textures: every rank encodes its own textures (weak scaling; c4: strong, texture_range). "
                          "slab: ONE --size^2 image of the workload split into block-row slabs over the ranks (strong "
@@ -223,14 +228,22 @@ def cpu_baseline(T, codec, comps, size, strategy, host_img):
             ref_info = {"value": rows * size / dt2 / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "reference",
                         "entry_point": "%sCompressor::Compress(%s)" % ({T.DXTC: "Dxtc", T.ETC: "Etc", T.PVRTC: "Pvrtc"}[compressor],
                                                                        {T.RGB: "kRGB", T.RGBA: "kRGBA"}[fmt])}
+    # (r06) the compiled reference's own figure -- "the reference's CPU path" -- rides at the top level of this
+    # object too, and in `sample`, not only in the nested `reference_single_thread`
+    ref_text = "; the compiled reference was not shipped with this run (oracle/_ref absent)"
+    if ref_info:
+        ref_text = "; compiled reference itself (oracle/_ref = /root/reference built in place, %s, 1 thread): %.1f Mpixels/s" \
+            % (ref_info["entry_point"], ref_info["value"])
     return {
         "reference_single_thread": ref_info,
+        "reference_value": ref_info["value"] if ref_info else None, "reference_cores": 1 if ref_info else None,
+        "reference_kind": "reference" if ref_info else None,
         "value": rows * size / dt / 1e6, "unit": "Mpixels/s", "cores": threads if codec not in (3, 4) else 1, "kind": "port",
         "single_thread_value": rows * size / dt1 / 1e6,
         "sample": "oracle/ic_oracle.c (plain-C port of the reference, -O2), %dx%d px of one workload texture, "
                   "%d timed pass(es) after one untimed, slab-parallel over block rows with %d pthreads (= %.1f s of "
-                  "single-core work); plus %d single-thread passes of the port and of the compiled reference"
-                  % (size, rows, reps, threads if codec not in (3, 4) else 1, reps * dt1, single_passes),
+                  "single-core work); plus %d single-thread passes of the port (%.1f Mpixels/s)%s"
+                  % (size, rows, reps, threads if codec not in (3, 4) else 1, reps * dt1, single_passes, rows * size / dt1 / 1e6, ref_text),
     }
 
 
@@ -628,20 +641,35 @@ def host_api_batch_leg(pkg, T, n_images=32, size=2048):
     return res
 
 
-def clock_under_load(torch, pkg, step, kernel_ms, launches):
-    """Effective shader clock while `launches` more launches of `step` run (the one-wave probe of the sustained leg, on a
-    second stream): every extra-config leg reports the clock its figure was taken at."""
+def clock_under_load(torch, pkg, step, kernel_ms, launches, stream=None):
+    """Effective shader clock of `launches` launches of `step` AND the mean duration of exactly those launches -> (MHz, ms per
+    launch), either None when the probe is unavailable.  r06: the probe wave (second stream) used to start
+    before the first of its launches was even enqueued, after seconds of idle time spent in the traffic passes -- it averaged the
+    chip's idle / ramping clock into a 10-launch window (c4: 2 269 MHz on one box, 2 403 on another, the kernel time the same)
+    while `valu_frac` divided by the kernel time of the EARLIER timed region.  Now: >= 150 ms of untimed launches first, the probe
+    wave is released by an event recorded behind them on the launch stream, the measured launches follow without a gap, the probe
+    sleeps for 80 % of their expected duration -- it only ever samples while this leg's kernels run -- and the kernel time that
+    goes with the clock is the one of the same launches (one HIP event on either side)."""
     try:
+        s = stream if stream is not None else torch.cuda.current_stream()
         buf = pkg.clock_probe_buffer()
         ps = torch.cuda.Stream()
+        for _ in range(max(launches, int(150.0 / max(kernel_ms, 1e-3)))):
+            step()
+        go = torch.cuda.Event()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        go.record(s)
+        ps.wait_event(go)
         res = pkg.clock_probe(max(200, int(kernel_ms * 1e3 * launches * 0.8)), ps, buf)
+        e0.record(s)
         for _ in range(launches):
             step()
+        e1.record(s)
         torch.cuda.synchronize()
         r = res()
-        return round(r["shader_MHz"], 1) if r else None
+        return (round(r["shader_MHz"], 1) if r else None), e0.elapsed_time(e1) / launches
     except Exception:
-        return None
+        return None, None
 
 
 def link_probe(ctx, mib=64, reps=3):
@@ -708,6 +736,15 @@ class Ctx:
         self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
         self.distributed, self.backend = distributed, backend
         self.on_gpu = getattr(device, "type", str(device)) == "cuda"
+        self.rccl = None      # image_compression_amd.RcclGather: the library's own gather (icamd_gather_blocks_rccl), nccl backend only
+        self.rccl_note = None  # why it is absent when it was asked for
+        self.leg = "start"    # what is running now: what the watchdog names when it fires
+
+    def gather_impl(self):
+        if self.rccl is not None:
+            return "icamd_gather_blocks_rccl (the library's C entry point: one grouped ncclSend / ncclRecv exchange on its own ncclComm_t)"
+        return "torch.distributed (dist.gather / batched isend-irecv), backend %s%s" % (
+            self.backend, "; the C entry point was not used: %s" % self.rccl_note if self.rccl_note else "")
 
     def sync(self):
         if self.on_gpu:
@@ -904,10 +941,13 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
                            "kernel": pkg.kernel_name(codec, comps), "kernel_ms": round(kernel_ms, 4),
                            "algorithmic_bytes_per_launch": int(algo)}
         # the clock this figure was taken at (DXT5 moves 835 <-> 1 264 Gpix/s with it, r04) and the VALU issue fraction
-        mhz = clock_under_load(torch, pkg, step, kernel_ms, max(steps, int(30.0 / max(kernel_ms, 1e-3)))) if ctx.on_gpu else None
+        mhz, window_ms = clock_under_load(torch, pkg, step, kernel_ms, max(steps, int(30.0 / max(kernel_ms, 1e-3))), stream) \
+            if ctx.on_gpu else (None, None)
         res["roofline"]["effective_clock_MHz"] = mhz
-        vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, kernel_ms, mhz, preset=name,
-                           live_insts=LIVE_VALU_INSTS.get((cfg["workload"], size, batch, content, strategy)))
+        res["roofline"]["clock_window_kernel_ms"] = None if window_ms is None else round(window_ms, 4)
+        # valu_frac: instructions x issue clocks over (SIMDs x clock x time) with clock AND time of the same launches
+        vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, window_ms if (mhz and window_ms) else kernel_ms, mhz,
+                           preset=name, live_insts=LIVE_VALU_INSTS.get((cfg["workload"], size, batch, content, strategy)))
         if vf:
             res["roofline"].update({k: vf[k] for k in ("valu_frac", "valu_wave_insts_per_block", "valu_profile", "valu_clock_MHz")})
         if verify:
@@ -944,7 +984,7 @@ def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_
         enc_done[slot].record(stream)
         with torch.cuda.stream(comm):
             comm.wait_event(enc_done[slot])
-            sharding.gather_to_root(outs[slot], gathered[slot], counts, ctx.rank, host_staged=ctx.backend == "gloo")
+            sharding.gather_to_root(outs[slot], gathered[slot], counts, ctx.rank, host_staged=ctx.backend == "gloo", rccl=ctx.rccl)
             gat_done[slot].record(comm)
 
     for slot in range(2):  # warm-up: communicator set-up, both buffers touched
@@ -980,8 +1020,8 @@ def gather_region(ctx, sharding, step_into, outs, counts, steps, stream, pixels_
     return {**bound, "value_with_gather": round(pixels_per_step_all * steps / elapsed_g / 1e6, 1),
             "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4), "gather_ms": round(gather_ms, 4),
             "gather_GBps_into_rank0": round(out_bytes_all * (world - 1) / world / (gather_ms * 1e-3) / 1e9, 2),
-            "gather": "dist.gather of the compressed output to rank 0 on a second stream, double-buffered, overlapping the "
-                      "next batch's encode (backend %s)" % ctx.backend,
+            "gather": "gather of the compressed output to rank 0 on a second stream, double-buffered, overlapping the "
+                      "next batch's encode: %s" % ctx.gather_impl(),
             "rank0_copy_matches": ok}
 
 
@@ -1034,14 +1074,14 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
 
     def encode_and_gather(k=None):
         step(k)
-        sharding.gather_to_root(out, bufs, counts, ctx.rank, host_staged=(ctx.backend == "gloo" and ctx.on_gpu))
+        sharding.gather_to_root(out, bufs, counts, ctx.rank, host_staged=(ctx.backend == "gloo" and ctx.on_gpu), rccl=ctx.rccl)
     try:
         elapsed_g, _ = timed_steps(ctx, encode_and_gather, steps, 2, 0.0, stream)
         res.update(gather_bound(probe, float(sum(counts)) * cols * block_bytes, ctx.world, px))
         res.update({"value_with_gather": round(px * steps / elapsed_g / 1e6, 1),
                     "ms_per_step_with_gather": round(elapsed_g / steps * 1e3, 4),
                     "gather": "slabs -> rank 0's final buffer (contiguous views), %s, not overlapped: one image's latency"
-                              % ("one rank: device copy" if ctx.world == 1 else "backend " + ctx.backend)})
+                              % ("one rank: device copy" if (ctx.world == 1 and ctx.rccl is None) else ctx.gather_impl())})
     except Exception as e:
         res.update({"value_with_gather": None, "gather_error": "%s: %s" % (type(e).__name__, e)})
     if ctx.rank == 0 and kernel_ms:
@@ -1088,6 +1128,56 @@ def slab_leg(ctx, pkg, sharding, workload, size, steps, content="noise", verify=
     if ctx.on_gpu:
         torch.cuda.empty_cache()
     return res
+
+
+def next_rows_leg(timeout_s=300):
+    """The SURVEY 8f "next" rows at 16 x 4096^2, device-resident, in the driver's line: scripts/bench_next_rows.py
+    --core in a child process (its own buffers and failures), every leg with its algorithmic GB/s, fraction of 8 TB/s and the parity
+    of image 0 of exactly the timed call against the oracle; `bars` are the round's stated targets and whether each leg meets them."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="icamd_next_rows_", suffix=".json", dir="/tmp")
+    os.close(fd)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_next_rows.py"), "--core", "--json", path],
+                           capture_output=True, text=True, timeout=timeout_s)
+        with open(path) as f:
+            d = json.load(f)
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    legs = {x["leg"]: {k: x[k] for k in ("algorithmic_GBps", "frac", "ms_per_call", "parity", "one_launch")} for x in d["legs"]}
+    bars = {"downsample dxt1 batched": 0.45, "downsample dxt5 batched": 0.45, "downsample dxt1": 0.30, "downsample dxt5": 0.30,
+            "transcode dxt1->etc1": 0.25}
+    return {"shape": d.get("shape"), "all_bit_exact": d.get("all_bit_exact"), "child_rc": r.returncode, "legs": legs,
+            "bars": {k: {"target_frac": v, "frac": (legs.get(k) or {}).get("frac"),
+                         "met": bool(legs.get(k) and legs[k]["frac"] >= v)} for k, v in bars.items()},
+            "note": "frac = algorithmic bytes (blocks in + blocks / pixels out) / time / 8 TB/s; `downsample <codec>` without "
+                    "`batched` is one icamd_downsample_device call per image, 16 calls per timed step"}
+
+
+def setup_rccl_gather(ctx, args, pkg, sharding):
+    """The library's own communicator for the gather legs (ctx.rccl).  Called after the headline measurement and under the
+    watchdog: its set-up is itself a collective that has never run between two real GPUs.  All ranks or none: a rank that failed
+    must not leave the others waiting in a grouped receive."""
+    if args.gather_impl != "c":
+        ctx.rccl_note = "--gather-impl torch"
+        return
+    if args.backend != "nccl":
+        ctx.rccl_note = "backend %s (ranks share a GPU or run on the CPU: RCCL wants one GPU per rank)" % args.backend
+        return
+    ctx.leg = "rccl communicator set-up (icamd_rccl_comm_init)"
+    try:
+        ctx.rccl = sharding.make_rccl_gather(pkg, ctx.rank, ctx.world, ctx.device)
+    except Exception as e:
+        ctx.rccl, ctx.rccl_note = None, "%s: %s" % (type(e).__name__, str(e)[:200])
+    ok_everywhere = ctx.min_over_ranks(1.0 if ctx.rccl is not None else 0.0)
+    if ok_everywhere != 1.0 and ctx.rccl is not None:
+        ctx.rccl.destroy()
+        ctx.rccl, ctx.rccl_note = None, "another rank could not create its communicator"
 
 
 def main():
@@ -1145,6 +1235,8 @@ def main():
 
     if args.shard == "slab":  # ONE large image over the ranks: the headline line of this mode
         probe = link_probe(ctx) if distributed else None
+        if distributed:
+            setup_rccl_gather(ctx, args, pkg, sharding)
         res = slab_leg(ctx, pkg, sharding, args.workload, args.size, args.steps, args.content, verify=not args.no_verify, probe=probe)
         res["link_probe"] = probe
         if rank == 0:
@@ -1159,6 +1251,8 @@ def main():
                                "world_size": world, "visible_gpus": n_dev, "kernel": pkg.kernel_name(codec, comps)}}
             line.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step", "unit", "steps", "scaling")})
             print(json.dumps(line))
+        if ctx.rccl is not None:
+            ctx.rccl.destroy()
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -1257,14 +1351,26 @@ def main():
 
     def watchdog_fire():
         if printed.acquire(False):
+            # every rank says on stderr which leg it was in (a deadlocked collective must leave a trace besides the
+            # `watchdog` field); the exit status stays 0 on purpose -- a non-zero rank would make the launcher tear the group down,
+            # possibly before rank 0's line is out, and the line itself says that it is incomplete
+            print("bench.py: rank %d: watchdog fired %.0f s after the headline measurement, still in leg '%s'"
+                  % (rank, args.watchdog_seconds, ctx.leg), file=sys.stderr, flush=True)
             if rank == 0:
-                result["watchdog"] = "extra legs still running %.0f s after the headline measurement: line printed without the unfinished ones" \
-                    % args.watchdog_seconds
-                try:
-                    print(json.dumps(result, default=str), flush=True)
-                except Exception:
-                    print(json.dumps({k: v for k, v in result.items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
-                                     "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "watchdog")}), flush=True)
+                result["watchdog"] = ("extra legs still running %.0f s after the headline measurement (rank 0 was in leg '%s'): line printed "
+                                      "without the unfinished ones" % (args.watchdog_seconds, ctx.leg))
+                text = None
+                for _ in range(5):  # the main thread may be adding a key at this very moment: try again rather than lose the legs
+                    try:
+                        text = json.dumps(dict(result), default=str)
+                        break
+                    except Exception:
+                        time.sleep(0.05)
+                if text is None:
+                    text = json.dumps({k: v for k, v in result.items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                      "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "watchdog")},
+                                      default=str)
+                print(text, flush=True)
             os._exit(0)
     watchdog = None
     if args.watchdog_seconds > 0:
@@ -1275,11 +1381,15 @@ def main():
     gather = None
     probe = None
     if distributed and not args.no_gather:
+        setup_rccl_gather(ctx, args, pkg, sharding)
+    if distributed and not args.no_gather:
+        ctx.leg = "link probe"
         try:
             probe = link_probe(ctx)
         except Exception as e:
             probe = None
             print("bench.py: link probe failed: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+        ctx.leg = "headline gather region"
         try:
             counts = [sharding.texture_range(args.total_textures, world, r) for r in range(world)] if args.total_textures \
                 else [(r * batch, (r + 1) * batch) for r in range(world)]
@@ -1291,6 +1401,9 @@ def main():
 
     if gather is not None:
         result.update(gather)
+    if distributed and not args.no_gather:
+        result["gather_impl"] = ctx.gather_impl()
+    ctx.leg = "rank 0's single-GPU legs (traffic, parity, cpu baseline, host api, sustained, single image)"
     result["link_probe"] = probe
     result["scaling_headline"] = (
         "`value` (every rank's compressed output stays in the HBM of the GPU that made it -- the texture pipeline's normal case) "
@@ -1373,6 +1486,9 @@ def main():
                                                           stream, bytes_per_px)
             except Exception as e:
                 result["single_image"] = "unavailable: %s: %s" % (type(e).__name__, e)
+        if world == 1 and args.preset == "c2" and args.content == "noise" and not args.no_next_rows:
+            ctx.leg = "next_rows"
+            result["next_rows"] = next_rows_leg()
         result["library"] = {"path": os.path.relpath(pkg.LIB_PATH, ROOT), "overridden": bool(pkg.LIB_OVERRIDDEN),
                              "version": pkg.lib().icamd_version().decode()}
     # ---- the other BASELINE configurations and the one-large-image slab legs, in the same line (every rank takes part).
@@ -1384,6 +1500,7 @@ def main():
         if not args.no_extra_configs:
             configs = {}
             for name in ("c3", "c4", "c5", "c5_4bpp"):
+                ctx.leg = "configs." + name
                 try:
                     configs[name] = preset_leg(ctx, pkg, sharding, name, args.extra_steps, verify=not args.no_verify,
                                                gather=not args.no_gather, probe=probe, live=not args.no_live_traffic)
@@ -1394,12 +1511,13 @@ def main():
                     # configuration is quoted on; flat tiles take the one-colour forms): the same leg on the other two contents
                     other = {}
                     for content in ("smooth", "flat"):
+                        ctx.leg = "configs.c4.other_contents." + content
                         try:
                             r = preset_leg(ctx, pkg, sharding, name, max(2, args.extra_steps // 2), content=content,
                                            verify=not args.no_verify, gather=False, live=not args.no_live_traffic)
                             other[content] = {k: r.get(k) for k in ("value", "unit", "ms_per_step", "steps", "parity", "data")}
                             rf = r.get("roofline") or {}
-                            other[content].update({k: rf.get(k) for k in ("frac", "valu_frac", "effective_clock_MHz", "kernel_ms",
+                            other[content].update({k: rf.get(k) for k in ("frac", "valu_frac", "effective_clock_MHz", "kernel_ms", "clock_window_kernel_ms",
                                                                            "valu_wave_insts_per_block", "valu_profile", "traffic")})
                         except Exception as e:
                             other[content] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -1408,17 +1526,24 @@ def main():
         if not args.no_slab:
             slabs = {}
             for key, wl, sz in (("c2_one_4096", "dxt1_rgba8", 4096), ("c3_one_8192", "dxt5_rgba8", 8192), ("one_16384", "dxt1_rgba8", 16384)):
+                ctx.leg = "slab." + key
                 try:
                     slabs[key] = slab_leg(ctx, pkg, sharding, wl, sz, args.extra_steps, verify=not args.no_verify, probe=probe)
                 except Exception as e:
                     slabs[key] = {"error": "%s: %s" % (type(e).__name__, e)}
             result["slab"] = slabs
+    ctx.leg = "done"
     if not printed.acquire(False):  # the watchdog is printing: let it finish
         time.sleep(30)
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if ctx.rccl is not None:
+        try:
+            ctx.rccl.destroy()
+        except Exception as e:
+            print("bench.py: rank %d: icamd_rccl_comm_destroy: %s" % (rank, e), file=sys.stderr)
     if distributed:
         if args.watchdog_seconds > 0:  # the final barrier must not hang the exit either
             bye = threading.Timer(60.0, lambda: os._exit(0))

@@ -42,7 +42,9 @@ EXPORTS = [
     "icamd_create_solid_device", "icamd_create_solid", "icamd_copy_subimage_device", "icamd_copy_subimage",
     "icamd_encode_batch_sharded_device", "icamd_clock_probe_device", "icamd_wall_clock_rate_khz",
     "icamd_container_size", "icamd_container_write",
+    "icamd_rccl_available", "icamd_rccl_get_unique_id", "icamd_rccl_comm_init", "icamd_rccl_comm_destroy", "icamd_gather_blocks_rccl",
 ]
+RCCL_UNIQUE_ID_BYTES = 128
 CONTAINER_DDS, CONTAINER_KTX, CONTAINER_PKM, CONTAINER_PVR = 0, 1, 2, 3
 
 _u32, _sz, _vp, _ci = ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
@@ -112,15 +114,15 @@ def lib():
                 L.icamd_pvrtc4_workspace_size.argtypes = [_u32, _u32]
             L.icamd_pvrtc2_set_workspace.restype = _ci
             L.icamd_pvrtc2_set_workspace.argtypes = [_vp, _sz]
-        if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_tune"):
-            L.icamd_pvrtc2_tune.restype = _ci
-            L.icamd_pvrtc2_tune.argtypes = [_ci, _ci]
             L.icamd_host_register.restype = _ci
             L.icamd_host_register.argtypes = [_vp, _sz]
             L.icamd_host_unregister.restype = _ci
             L.icamd_host_unregister.argtypes = [_vp]
             L.icamd_pvrtc2_decompress.restype = _ci
             L.icamd_pvrtc2_decompress.argtypes = [_u32, _vp, _sz, _vp, _sz]
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_pvrtc2_tune"):  # r05 entry point (older A/B builds lack it)
+            L.icamd_pvrtc2_tune.restype = _ci
+            L.icamd_pvrtc2_tune.argtypes = [_ci, _ci]
         if not LIB_OVERRIDDEN or hasattr(L, "icamd_pad_batch_device"):  # r05 entry points
             L.icamd_pad_batch_device.restype = _ci
             L.icamd_pad_batch_device.argtypes = [_ci, _ci, _ci, _u32, _u32, _u32, _vp, _sz, _u32, _u32, _vp, _sz, _sz, _vp]
@@ -144,6 +146,17 @@ def lib():
             L.icamd_clock_probe_device.restype = _ci
             L.icamd_clock_probe_device.argtypes = [_vp, _u32, _vp]
             L.icamd_wall_clock_rate_khz.restype = _u32
+        if not LIB_OVERRIDDEN or hasattr(L, "icamd_gather_blocks_rccl"):  # r06 entry points
+            L.icamd_rccl_available.restype = _ci
+            L.icamd_rccl_available.argtypes = []
+            L.icamd_rccl_get_unique_id.restype = _ci
+            L.icamd_rccl_get_unique_id.argtypes = [_vp]
+            L.icamd_rccl_comm_init.restype = _ci
+            L.icamd_rccl_comm_init.argtypes = [ctypes.POINTER(_vp), _ci, _ci, _vp]
+            L.icamd_rccl_comm_destroy.restype = _ci
+            L.icamd_rccl_comm_destroy.argtypes = [_vp]
+            L.icamd_gather_blocks_rccl.restype = _ci
+            L.icamd_gather_blocks_rccl.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp]
         L.icamd_device_count.restype = _ci
         L.icamd_last_error.restype = ctypes.c_char_p
         L.icamd_version.restype = ctypes.c_char_p
@@ -434,6 +447,9 @@ def pad_batch_device(compressor, fmt, blocks, compressed_height, compressed_widt
     """icamd_pad_batch_device (extension): blocks = [n, bytes] device tensor of equally shaped grids -> [n, bytes] padded."""
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous() and blocks.dim() == 2
     per = ((padded_height + 3) // 4) * ((padded_width + 3) // 4) * _block_bytes(compressor, fmt)
+    need = ((compressed_height + 3) // 4) * ((compressed_width + 3) // 4) * _block_bytes(compressor, fmt)
+    if blocks.shape[1] < need:
+        raise ValueError("pad_batch_device: %d bytes per image, the source grid takes %d" % (blocks.shape[1], need))
     out = torch.empty((blocks.shape[0], max(per, 1)), dtype=torch.uint8, device=blocks.device)
     st = lib().icamd_pad_batch_device(compressor, etc_strategy, fmt, compressed_height, compressed_width, blocks.shape[0],
                                       ctypes.c_void_p(blocks.data_ptr()), blocks.shape[1], padded_height, padded_width,
@@ -446,6 +462,9 @@ def copy_subimage_batch_device(compressor, fmt, blocks, compressed_height, compr
     """icamd_copy_subimage_batch_device (extension): the same window of every grid of blocks = [n, bytes]."""
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous() and blocks.dim() == 2
     per = ((height + 3) // 4) * ((width + 3) // 4) * _block_bytes(compressor, fmt)
+    need = ((compressed_height + 3) // 4) * ((compressed_width + 3) // 4) * _block_bytes(compressor, fmt)
+    if blocks.shape[1] < need:
+        raise ValueError("copy_subimage_batch_device: %d bytes per image, the source grid takes %d" % (blocks.shape[1], need))
     out = torch.empty((blocks.shape[0], max(per, 1)), dtype=torch.uint8, device=blocks.device)
     st = lib().icamd_copy_subimage_batch_device(compressor, fmt, compressed_height, compressed_width, blocks.shape[0],
                                                 ctypes.c_void_p(blocks.data_ptr()), blocks.shape[1], start_row, start_column,
@@ -565,3 +584,48 @@ def clock_probe(duration_us, stream, out=None):
         return {"shader_MHz": cyc / ticks * khz / 1e3, "shader_cycles": cyc, "ref_ticks": ticks, "ref_clock_kHz": khz,
                 "interval_ms": ticks / khz}
     return result
+
+
+class RcclGather:
+    """The product's own gather of the compressed output (icamd_gather_blocks_rccl: one grouped ncclSend / ncclRecv exchange
+    into rank `root`'s HBM).  torch.distributed is only used to hand rank 0's ncclUniqueId to the other ranks (any transport
+    would do: the C entry points take the 128 bytes); the communicator and the collective are the library's."""
+
+    def __init__(self, rank, world, broadcast_bytes):
+        """broadcast_bytes(bytes or None) -> bytes: hands rank 0's argument to every rank (collective)."""
+        L = lib()
+        if not L.icamd_rccl_available():
+            raise BackendError("librccl could not be bound: %s" % L.icamd_last_error().decode())
+        self.rank, self.world = rank, world
+        self.comm = ctypes.c_void_p()
+        uid = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
+        if rank == 0:
+            _check(L.icamd_rccl_get_unique_id(uid), "icamd_rccl_get_unique_id")
+        raw = broadcast_bytes(bytes(uid) if rank == 0 else None)
+        uid = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)(*raw)
+        st = L.icamd_rccl_comm_init(ctypes.byref(self.comm), world, rank, uid)
+        if st != OK:
+            raise BackendError("icamd_rccl_comm_init failed with status %d: %s" % (st, L.icamd_last_error().decode()))
+
+    def gather(self, local, bufs, counts_bytes, root=0, stream=None):
+        """local: this rank's uint8 device tensor (counts_bytes[rank] bytes); bufs: on `root`, one device tensor per rank (any
+        placement: their offsets from the lowest address are passed on), elsewhere None.  Enqueued, not synchronised."""
+        n = self.world
+        counts = (ctypes.c_size_t * n)(*[int(c) for c in counts_bytes])
+        base, offs = None, None
+        if self.rank == root:
+            ptrs = [b.data_ptr() for b in bufs]
+            lo = min(p for p, c in zip(ptrs, counts_bytes) if c > 0) if any(c > 0 for c in counts_bytes) else 0
+            base = ctypes.c_void_p(lo)
+            offs = (ctypes.c_size_t * n)(*[(p - lo) if c > 0 else 0 for p, c in zip(ptrs, counts_bytes)])
+        st = lib().icamd_gather_blocks_rccl(self.comm, self.rank, n, root, counts,
+                                            ctypes.c_void_p(local.data_ptr()) if local.numel() else None, base, offs,
+                                            _stream_handle(stream))
+        if st != OK:
+            raise BackendError("icamd_gather_blocks_rccl failed with status %d: %s" % (st, lib().icamd_last_error().decode()))
+
+    def destroy(self):
+        if self.comm:
+            lib().icamd_rccl_comm_destroy(self.comm)
+            self.comm = ctypes.c_void_p()
+

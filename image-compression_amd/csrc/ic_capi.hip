@@ -13,26 +13,76 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 #include "containers.h"
+#include "ic_abi.h"
 #include "ic_launch.h"
 
-namespace {
+// Error text and the exception barrier of the C ABI: declared in ic_abi.h (shared with rccl_gather.hip), defined here.
+namespace icamd {
+thread_local char g_last_error[kErrorChars] = "";
 
-thread_local std::string g_last_error;
+void set_last_error(const char *text) noexcept {
+  std::snprintf(g_last_error, kErrorChars, "%s", text ? text : "");
+}
 
-int fail(int code, const char *what, hipError_t e = hipSuccess) {
-  char buf[256];
+int fail(int code, const char *what, hipError_t e) noexcept {
   if (e != hipSuccess)
-    std::snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    std::snprintf(g_last_error, kErrorChars, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
   else
-    std::snprintf(buf, sizeof buf, "%s", what);
-  g_last_error = buf;
+    std::snprintf(g_last_error, kErrorChars, "%s", what);
   return code;
 }
+
+int abi_exception() noexcept {
+  try {
+    throw;
+  } catch (const std::bad_alloc &) {
+    return fail(ICAMD_ERR_ALLOC, "out of host memory (std::bad_alloc)");
+  } catch (const std::system_error &e) {
+    char buf[kErrorChars];
+    std::snprintf(buf, sizeof buf, "system resource unavailable (std::system_error: %s)", e.what());
+    return fail(ICAMD_ERR_ALLOC, buf);
+  } catch (const std::exception &e) {
+    char buf[kErrorChars];
+    std::snprintf(buf, sizeof buf, "unexpected C++ exception: %s", e.what());
+    return fail(ICAMD_ERR_HIP, buf);
+  } catch (...) {
+    return fail(ICAMD_ERR_HIP, "unexpected C++ exception");
+  }
+}
+}  // namespace icamd
+
+namespace {
+using icamd::abi_exception;
+using icamd::fail;
+using icamd::g_last_error;
+using icamd::kErrorChars;
+using icamd::set_last_error;
+
+// Worker threads of the two batch entry points.  A worker's body never lets an exception out (that would be std::terminate);
+// the guard joins whatever was started before the vectors the workers write to go out of scope, on every path out.
+struct JoinAll {
+  std::vector<std::thread> &threads;
+  ~JoinAll() {
+    for (std::thread &t : threads)
+      if (t.joinable()) t.join();
+  }
+};
+// A device list is a handful of GPUs, possibly each named a few times (two workers per GPU overlap their copies): a longer
+// list is a caller's mistake, and one worker thread per entry must not be something a caller can ask 10 000 of.
+constexpr int kMaxDeviceListEntries = 256;
+// Text of a worker's first failure (fixed size: written from inside the worker without allocating).
+struct WorkerError {
+  char text[kErrorChars] = "";
+  bool empty() const { return text[0] == 0; }
+  void set(const char *t) noexcept { std::snprintf(text, sizeof text, "%s", t ? t : ""); }
+};
 
 #define ICAMD_HIP(call, what)                                   \
   do {                                                          \
@@ -147,11 +197,57 @@ struct TlsStaging {
     return *p;
   }
   ~TlsStaging() {
-    if (p) pool_give(std::unique_ptr<Staging>(p));  // no HIP call here
+    if (!p) return;
+    try {
+      pool_give(std::unique_ptr<Staging>(p));  // no HIP call here
+    } catch (...) {
+      // (the pool could not grow: the staging's device buffers stay allocated until the process ends)
+    }
   }
 };
 thread_local TlsStaging g_tls_staging;
 Staging &tls_staging() { return g_tls_staging.get(); }
+
+// ---- one large image per call as two concurrent bands (experiment knob) ----
+// ICAMD_SPLIT_SINGLE=1 (read once): icamd_encode_device / icamd_compress_device calls with ONE image of at least
+// ICAMD_SPLIT_SINGLE_MIN_BLOCKS (default 2^20 = one 4096^2 image) 4x4 blocks run as two kernels, the lower band on a per-thread
+// side stream between a fork and a join event.  What it measured is in profiles/r06_ab_single_image_split.log and DESIGN.md 5.
+int split_single_mode() {
+  static const int mode = [] { const char *e = getenv("ICAMD_SPLIT_SINGLE"); return e && e[0] == '1' ? 1 : 0; }();
+  return mode;
+}
+uint64_t split_single_min_blocks() {
+  static const uint64_t n = [] {
+    const char *e = getenv("ICAMD_SPLIT_SINGLE_MIN_BLOCKS");
+    const long long v = e && *e ? atoll(e) : 0;
+    return v > 0 ? (uint64_t)v : (1ull << 20);
+  }();
+  return n;
+}
+struct SplitLane {
+  int device = -1;
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+// The calling thread's side stream and events on the current device (created on first use, re-created when the thread moves to
+// another device; never destroyed: no HIP call may run from a thread_local destructor).  nullptr: could not be created.
+SplitLane *tls_split_lane() {
+  static thread_local SplitLane lane;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (lane.device != dev || !lane.side) {
+    lane = SplitLane();
+    if (hipStreamCreateWithFlags(&lane.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&lane.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&lane.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      lane = SplitLane();
+      return nullptr;
+    }
+    lane.device = dev;
+  }
+  return &lane;
+}
 
 int require_device() {
   int n = 0;
@@ -237,13 +333,13 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 const char *icamd_version(void) { return "image-compression_amd 0.5 (gfx950)"; }
-const char *icamd_last_error(void) { return g_last_error.c_str(); }
+const char *icamd_last_error(void) { return g_last_error; }
 
-int icamd_device_count(void) {
+int icamd_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} ICAMD_ABI_CATCH
 
 const char *icamd_kernel_name(int codec, int src_components) {
   switch (codec) {
@@ -255,13 +351,13 @@ const char *icamd_kernel_name(int codec, int src_components) {
   return "";
 }
 
-int icamd_supports_format(int compressor, int format) {
+int icamd_supports_format(int compressor, int format) try {
   if (format_components(format) == 0) return 0;
   if (compressor == ICAMD_COMPRESSOR_DXTC) return 1;                      // dxtc.cc:707-710
   if (compressor == ICAMD_COMPRESSOR_ETC) return format == ICAMD_RGB;     // etc.cc:713-717
   if (compressor == ICAMD_COMPRESSOR_PVRTC) return format == ICAMD_RGBA;  // pvrtc.cc:607-609
   return 0;
-}
+} ICAMD_ABI_CATCH
 
 size_t icamd_compute_compressed_data_size(int compressor, int format, uint32_t height, uint32_t width) {
   if (compressor == ICAMD_COMPRESSOR_PVRTC) return (size_t)(width * height / 4);  // pvrtc.cc:631-634 (uint32 product)
@@ -282,7 +378,7 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
                         uint32_t height, uint32_t width, uint32_t grid_height, uint32_t grid_width,
                         uint32_t row_stride_bytes, uint32_t n_images,
                         size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
-                        const void *d_src, void *d_dst, void *hip_stream) {
+                        const void *d_src, void *d_dst, void *hip_stream) try {
   if (!d_src || !d_dst || height == 0 || width == 0) return ICAMD_FALSE;
   if (src_components != 3 && src_components != 4) return fail(ICAMD_ERR_ARG, "src_components must be 3 or 4");
   if (n_images == 0) return ICAMD_OK;
@@ -330,15 +426,40 @@ int icamd_encode_device(int codec, int etc_strategy, int src_components, int swa
   P.swap_rb = swap_rb ? 1u : 0u;
   P.etc_strategy = (uint32_t)etc_strategy;
   P.log2_tile_cols = P.tile_row0 = P.force_gather = 0;
-  if (codec == ICAMD_ETC1)
-    ICAMD_HIP(icamd::launch_etc1(src_components, P, stream), "launch etc1");
-  else
-    ICAMD_HIP(icamd::launch_dxt(codec, src_components, P, stream), "launch dxt");
+  auto launch = [&](const icamd::GridParams &G, hipStream_t s) {
+    return codec == ICAMD_ETC1 ? icamd::launch_etc1(src_components, G, s) : icamd::launch_dxt(codec, src_components, G, s);
+  };
+  // ONE large image per call: optionally as two bands of block rows, the second on a side stream that is
+  // forked from and joined back into the caller's stream by events (legal under stream capture too).  Off by default: see
+  // split_single_mode() for what it measured.
+  if (n_images == 1 && split_single_mode() != 0 && (uint64_t)P.block_rows * P.block_cols >= split_single_min_blocks() && P.block_rows >= 2) {
+    SplitLane *lane = tls_split_lane();
+    if (lane) {
+      const uint32_t top = P.block_rows / 2u;
+      icamd::GridParams A = P, B = P;
+      A.block_rows = top;
+      A.height = std::min(height, top * 4u);
+      B.block_rows = P.block_rows - top;
+      B.height = height > top * 4u ? height - top * 4u : 0u;
+      if (B.height != 0) {  // (a CompressAndPad grid whose lower band lies wholly below the image is not split)
+        B.src = P.src + (size_t)top * 4u * row_stride_bytes;
+        B.dst = P.dst + (size_t)top * P.block_cols * (codec == ICAMD_DXT5 ? 16u : 8u);
+        ICAMD_HIP(hipEventRecord(lane->fork, stream), "split: fork event");
+        ICAMD_HIP(hipStreamWaitEvent(lane->side, lane->fork, 0), "split: fork wait");
+        ICAMD_HIP(launch(B, lane->side), "launch (lower band)");
+        ICAMD_HIP(launch(A, stream), "launch (upper band)");
+        ICAMD_HIP(hipEventRecord(lane->join, lane->side), "split: join event");
+        ICAMD_HIP(hipStreamWaitEvent(stream, lane->join, 0), "split: join wait");
+        return ICAMD_OK;
+      }
+    }
+  }
+  ICAMD_HIP(launch(P, stream), codec == ICAMD_ETC1 ? "launch etc1" : "launch dxt");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint32_t n_blocks, const void *d_src,
-                                      void *d_dst_region, void *hip_stream) {
+                                      void *d_dst_region, void *hip_stream) try {
   if (!d_src || !d_dst_region || n_blocks == 0) return ICAMD_FALSE;
   if (!is_pow2(size) || size < 8) return ICAMD_FALSE;  // pvrtc.cc:640-646
   if (size >= 65536u) return ICAMD_FALSE;              // as icamd_encode_device: the kernels index pixels with 32 bits
@@ -360,21 +481,21 @@ int icamd_pvrtc2_encode_region_device(uint32_t size, uint32_t first_block, uint3
   P.region_blocks = n_blocks;
   ICAMD_HIP(icamd::launch_pvrtc2(P, static_cast<hipStream_t>(hip_stream)), "launch pvrtc2 region");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
-int icamd_host_register(void *host_ptr, size_t bytes) {
+int icamd_host_register(void *host_ptr, size_t bytes) try {
   if (!host_ptr || bytes == 0) return fail(ICAMD_ERR_ARG, "icamd_host_register: null buffer");
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   ICAMD_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault), "hipHostRegister");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
-int icamd_host_unregister(void *host_ptr) {
+int icamd_host_unregister(void *host_ptr) try {
   if (!host_ptr) return fail(ICAMD_ERR_ARG, "icamd_host_unregister: null buffer");
   ICAMD_HIP(hipHostUnregister(host_ptr), "hipHostUnregister");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 size_t icamd_pvrtc2_workspace_size(uint32_t size, uint32_t n_images) {
   if (!is_pow2(size) || size < 8) return 0;
@@ -386,7 +507,7 @@ size_t icamd_pvrtc4_workspace_size(uint32_t size, uint32_t n_images) {
   return icamd::pvrtc4_workspace_bytes(size, n_images);
 }
 
-int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
+int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) try {
   if (d_workspace && reinterpret_cast<uintptr_t>(d_workspace) % 8u) return fail(ICAMD_ERR_ARG, "workspace must be 8-byte aligned");
   if (d_workspace) {
     // the kernels of this thread's later calls write through this pointer: it must be device memory of the current device
@@ -400,19 +521,19 @@ int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes) {
   }
   icamd::pvrtc2_set_workspace(d_workspace, bytes);
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
-int icamd_pvrtc2_tune(int mode, int log2_strip) {
+int icamd_pvrtc2_tune(int mode, int log2_strip) try {
   if (mode < 0 || mode > 2) return fail(ICAMD_ERR_ARG, "icamd_pvrtc2_tune: mode must be 0 (auto), 1 (two kernels) or 2 (one pass)");
   icamd::pvrtc2_tune(mode, log2_strip);
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
                                   uint32_t height, uint32_t width,
                                   uint32_t padded_height, uint32_t padded_width,
                                   uint32_t padding_bytes_per_row,
-                                  const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) {
+                                  const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) try {
   if (compressor == ICAMD_COMPRESSOR_PVRTC) return ICAMD_FALSE;  // pvrtc.cc:684-691
   // dxtc.cc:799-818 / etc.cc:787-800
   if (!d_buffer || !d_out || height == 0 || width == 0) return ICAMD_FALSE;
@@ -424,11 +545,11 @@ int icamd_compress_and_pad_device(int compressor, int etc_strategy, int format,
   if (out_size != need) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
   return icamd_encode_device(codec, etc_strategy, comps, swap, height, width, gh, gw,
                              width * (uint32_t)comps + padding_bytes_per_row, 1, 0, 0, d_buffer, d_out, hip_stream);
-}
+} ICAMD_ABI_CATCH
 
 int icamd_compress_device(int compressor, int etc_strategy, int format,
                           uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
-                          const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) {
+                          const void *d_buffer, void *d_out, size_t out_size, void *hip_stream) try {
   if (compressor == ICAMD_COMPRESSOR_PVRTC) {
     // pvrtc.cc:636-667.  `format` is deliberately not validated (neither does the reference).
     if (!d_buffer || !d_out || height == 0 || width == 0) return ICAMD_FALSE;
@@ -442,7 +563,7 @@ int icamd_compress_device(int compressor, int etc_strategy, int format,
   }
   return icamd_compress_and_pad_device(compressor, etc_strategy, format, height, width, height, width,
                                        padding_bytes_per_row, d_buffer, d_out, out_size, hip_stream);
-}
+} ICAMD_ABI_CATCH
 
 // Measured on the MI355X box (r01, 32 x 2048^2 kRGB -> DXT1, workers on one device): pageable copies 21 GB/s with one
 // worker; page-locked mirrors 10 / 14 / 20 / 22 GB/s with 1 / 2 / 4 / 8 workers -- the extra CPU memcpy costs more
@@ -545,17 +666,17 @@ static int compress_host_common(Staging &st, bool pinned, bool and_pad, int comp
 }
 
 int icamd_compress(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
-                   uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out, size_t out_size) {
+                   uint32_t padding_bytes_per_row, const uint8_t *buffer, uint8_t *out, size_t out_size) try {
   return compress_host_common(tls_staging(), false, false, compressor, etc_strategy, format, height, width, height, width,
                               padding_bytes_per_row, buffer, out, out_size);
-}
+} ICAMD_ABI_CATCH
 
 int icamd_compress_and_pad(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
                            uint32_t padded_height, uint32_t padded_width, uint32_t padding_bytes_per_row,
-                           const uint8_t *buffer, uint8_t *out, size_t out_size) {
+                           const uint8_t *buffer, uint8_t *out, size_t out_size) try {
   return compress_host_common(tls_staging(), false, true, compressor, etc_strategy, format, height, width, padded_height,
                               padded_width, padding_bytes_per_row, buffer, out, out_size);
-}
+} ICAMD_ABI_CATCH
 
 // One launch: fewer than 2^31 blocks (the decode kernels index blocks with 32 bits).
 static int decode_launch(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t row_stride,
@@ -582,7 +703,7 @@ static int decode_launch(int codec, int swap_rb, uint32_t height, uint32_t width
 
 int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
                         uint32_t n_images, size_t src_image_stride_bytes, size_t dst_image_stride_bytes,
-                        const void *d_blocks, void *d_pixels, void *hip_stream) {
+                        const void *d_blocks, void *d_pixels, void *hip_stream) try {
   if (!d_blocks || !d_pixels || height == 0 || width == 0) return ICAMD_FALSE;
   if (codec != ICAMD_DXT1 && codec != ICAMD_DXT5 && codec != ICAMD_ETC1 && codec != ICAMD_PVRTC2 && codec != ICAMD_PVRTC4)
     return ICAMD_FALSE;
@@ -633,10 +754,10 @@ int icamd_decode_device(int codec, int swap_rb, uint32_t height, uint32_t width,
       if (rc != ICAMD_OK) return rc;
     }
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width, uint32_t padding_bytes_per_row,
-                     const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) {
+                     const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) try {
   if (!blocks || !out || height == 0 || width == 0) return ICAMD_FALSE;
   int codec, comps;
   bool swap;
@@ -660,23 +781,23 @@ int icamd_decompress(int compressor, int format, uint32_t height, uint32_t width
   ICAMD_HIP(hipMemcpyAsync(out, st.d_out, need, hipMemcpyDeviceToHost, s), "D2H copy");
   ICAMD_HIP(hipStreamSynchronize(s), "stream synchronize");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 // EXTENSION (parity unpinned, see icamd_decode_device): host-buffer PVRTC 2bpp decode.  Kept apart from
 // icamd_decompress, which answers ICAMD_FALSE for PVRTC like the reference (pvrtc_compressor.cc:669-672).
-int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) {
+int icamd_pvrtc2_decompress(uint32_t size, const uint8_t *blocks, size_t blocks_size, uint8_t *out, size_t out_size) try {
   if (!blocks || !out || !is_pow2(size) || size < 8) return ICAMD_FALSE;
   if (blocks_size != (size_t)size * size / 4 || out_size != (size_t)size * size * 4) return ICAMD_FALSE;
   return staged_blockop(blocks, blocks_size, out, out_size, false, [&](void *din, void *dout, hipStream_t s) {
     return icamd_decode_device(ICAMD_PVRTC2, 0, size, size, 0, 1, 0, 0, din, dout, s);
   });
-}
+} ICAMD_ABI_CATCH
 
 // ---- compressed-domain operations
 
 int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, uint32_t n_images,
                            const void *d_blocks, size_t src_image_stride_bytes, uint32_t ph, uint32_t pw, void *d_out,
-                           size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
+                           size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) try {
   int codec;
   if (!d_blocks || !d_out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
   if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
@@ -686,7 +807,9 @@ int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_
   P.out_rows = num_blocks4(ph); P.out_cols = num_blocks4(pw);
   if (P.in_rows == 0 || P.in_cols == 0 || P.out_rows < P.in_rows || P.out_cols < P.in_cols) return ICAMD_FALSE;
   if (out_size_per_image != icamd_encoded_size(codec, ph, pw)) return ICAMD_FALSE;
-  if (n_images > 1 && (src_image_stride_bytes < icamd_encoded_size(codec, ch, cw) || dst_image_stride_bytes < out_size_per_image))
+  // (a non-zero stride is checked for one image too: a caller that passes one states how far its buffer reaches)
+  if (((n_images > 1 || src_image_stride_bytes != 0) && src_image_stride_bytes < icamd_encoded_size(codec, ch, cw)) ||
+      ((n_images > 1 || dst_image_stride_bytes != 0) && dst_image_stride_bytes < out_size_per_image))
     return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
@@ -711,16 +834,16 @@ int icamd_pad_batch_device(int compressor, int etc_strategy, int format, uint32_
     ICAMD_HIP(icamd::launch_pad(codec, P, static_cast<hipStream_t>(hip_stream)), "launch pad");
   }
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_pad_device(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const void *d_blocks,
-                     uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) {
+                     uint32_t ph, uint32_t pw, void *d_out, size_t out_size, void *hip_stream) try {
   return icamd_pad_batch_device(compressor, etc_strategy, format, ch, cw, 1, d_blocks, 0, ph, pw, d_out, 0, out_size, hip_stream);
-}
+} ICAMD_ABI_CATCH
 
 int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, uint32_t n_images,
                                   const void *d_blocks, size_t src_image_stride_bytes, void *d_out,
-                                  size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
+                                  size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) try {
   int codec;
   if (!d_blocks || !d_out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
   if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
@@ -761,14 +884,14 @@ int icamd_downsample_batch_device(int compressor, int etc_strategy, int format, 
     ICAMD_HIP(icamd::launch_downsample(codec, P, static_cast<hipStream_t>(hip_stream)), "launch downsample");
   }
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_downsample_device(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw,
-                            const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) {
+                            const void *d_blocks, void *d_out, size_t out_size, void *hip_stream) try {
   return icamd_downsample_batch_device(compressor, etc_strategy, format, uh, uw, 1, d_blocks, 0, d_out, 0, out_size, hip_stream);
-}
+} ICAMD_ABI_CATCH
 
-int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream) {
+int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hip_stream) try {
   if (!d_blocks) return ICAMD_FALSE;
   if (reinterpret_cast<uintptr_t>(d_blocks) % 8u) return fail(ICAMD_ERR_ARG, "block pointer must be 8-byte aligned");
   if (n_bytes < 8) return ICAMD_OK;
@@ -781,10 +904,10 @@ int icamd_transcode_dxt1_to_etc1_device(void *d_blocks, size_t n_bytes, void *hi
                                                    static_cast<hipStream_t>(hip_stream)), "launch transcode");
   }
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_pad(int compressor, int etc_strategy, int format, uint32_t ch, uint32_t cw, const uint8_t *blocks,
-              uint32_t ph, uint32_t pw, uint8_t *out, size_t out_size) {
+              uint32_t ph, uint32_t pw, uint8_t *out, size_t out_size) try {
   int codec;
   if (!blocks || !out || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
   if (num_blocks4(ph) < num_blocks4(ch) || num_blocks4(pw) < num_blocks4(cw)) return ICAMD_FALSE;
@@ -793,10 +916,10 @@ int icamd_pad(int compressor, int etc_strategy, int format, uint32_t ch, uint32_
                         [&](void *din, void *dout, hipStream_t s) {
                           return icamd_pad_device(compressor, etc_strategy, format, ch, cw, din, ph, pw, dout, out_size, s);
                         });
-}
+} ICAMD_ABI_CATCH
 
 int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uh, uint32_t uw, const uint8_t *blocks,
-                     uint8_t *out, size_t out_size) {
+                     uint8_t *out, size_t out_size) try {
   int codec;
   if (!blocks || !out || uh == 0 || uw == 0 || !blockop_codec(compressor, format, &codec)) return ICAMD_FALSE;
   const uint32_t r = num_blocks4(uh), c = num_blocks4(uw);
@@ -806,21 +929,22 @@ int icamd_downsample(int compressor, int etc_strategy, int format, uint32_t uh, 
                         [&](void *din, void *dout, hipStream_t s) {
                           return icamd_downsample_device(compressor, etc_strategy, format, uh, uw, din, dout, out_size, s);
                         });
-}
+} ICAMD_ABI_CATCH
 
-int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes) {
+int icamd_transcode_dxt1_to_etc1(uint8_t *blocks, size_t n_bytes) try {
   if (!blocks) return ICAMD_FALSE;
   if (n_bytes < 8) return ICAMD_OK;
   return staged_blockop(blocks, n_bytes, blocks, n_bytes - n_bytes % 8, true, [&](void *din, void *, hipStream_t s) {
     return icamd_transcode_dxt1_to_etc1_device(din, n_bytes, s);
   });
-}
+} ICAMD_ABI_CATCH
 
 int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t height, uint32_t width,
                          uint32_t padding_bytes_per_row, uint32_t n_images, const uint8_t *const *buffers,
-                         uint8_t *const *outs, size_t out_size, const int *devices, int n_devices, int *statuses) {
+                         uint8_t *const *outs, size_t out_size, const int *devices, int n_devices, int *statuses) try {
   if (n_images == 0) return ICAMD_OK;
   if (!buffers || !outs || !devices || n_devices <= 0) return fail(ICAMD_ERR_ARG, "icamd_compress_batch: null list");
+  if (n_devices > kMaxDeviceListEntries) return fail(ICAMD_ERR_ARG, "icamd_compress_batch: device list longer than 256 entries");
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
   int visible = 0;
@@ -828,37 +952,58 @@ int icamd_compress_batch(int compressor, int etc_strategy, int format, uint32_t 
   for (int d = 0; d < n_devices; ++d)
     if (devices[d] < 0 || devices[d] >= visible) return fail(ICAMD_ERR_ARG, "icamd_compress_batch: bad device ordinal");
   std::vector<int> local(n_images, ICAMD_OK);
-  std::vector<std::string> errors((size_t)n_devices);
+  std::vector<WorkerError> errors((size_t)n_devices);
   std::vector<std::thread> workers;
   workers.reserve((size_t)n_devices);
-  for (int d = 0; d < n_devices; ++d) {
-    workers.emplace_back([&, d]() {
-      // each worker owns its device context and a pooled Staging (stream, device buffers, pinned host mirrors)
-      if (hipSetDevice(devices[d]) != hipSuccess) {
-        for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) local[i] = ICAMD_ERR_HIP;
-        errors[(size_t)d] = "hipSetDevice failed";
-        return;
+  int not_started_from = n_devices;  // list entries from here on have no worker (thread creation failed)
+  {
+    JoinAll join_on_every_path_out{workers};
+    for (int d = 0; d < n_devices && (uint32_t)d < n_images; ++d) {
+      try {
+        workers.emplace_back([&, d]() noexcept {
+          auto fail_all = [&](int code, const char *what) {
+            for (uint64_t i = (uint64_t)d; i < n_images; i += (uint64_t)n_devices) local[i] = code;
+            if (errors[(size_t)d].empty()) errors[(size_t)d].set(what);
+          };
+          uint64_t reached = (uint64_t)d;  // the image being worked on: what an exception leaves undone starts here
+          try {
+            // each worker owns its device context and a pooled Staging (stream, device buffers, pinned host mirrors)
+            if (hipSetDevice(devices[d]) != hipSuccess) return fail_all(ICAMD_ERR_HIP, "hipSetDevice failed");
+            std::unique_ptr<Staging> st = pool_take(devices[d]);
+            for (; reached < n_images; reached += (uint64_t)n_devices) {
+              const uint32_t i = (uint32_t)reached;
+              local[i] = compress_host_common(*st, kBatchPinnedStaging, false, compressor, etc_strategy, format, height, width, height, width,
+                                              padding_bytes_per_row, buffers[i], outs[i], out_size);
+              if (local[i] < 0 && errors[(size_t)d].empty()) errors[(size_t)d].set(g_last_error);
+            }
+            pool_give(std::move(st));
+          } catch (...) {
+            const int code = abi_exception();
+            for (uint64_t i = reached; i < n_images; i += (uint64_t)n_devices) local[i] = code;
+            if (errors[(size_t)d].empty()) errors[(size_t)d].set(g_last_error);
+          }
+        });
+      } catch (...) {  // std::system_error from the thread's creation (or bad_alloc): the workers started so far finish
+        (void)abi_exception();
+        not_started_from = d;
+        break;
       }
-      std::unique_ptr<Staging> st = pool_take(devices[d]);
-      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) {
-        local[i] = compress_host_common(*st, kBatchPinnedStaging, false, compressor, etc_strategy, format, height, width, height, width,
-                                        padding_bytes_per_row, buffers[i], outs[i], out_size);
-        if (local[i] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
-      }
-      pool_give(std::move(st));
-    });
+    }
+  }  // all started workers joined
+  for (int d = not_started_from; d < n_devices; ++d) {
+    for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) local[i] = ICAMD_ERR_ALLOC;
+    errors[(size_t)d].set("icamd_compress_batch: could not start a worker thread");
   }
-  for (std::thread &t : workers) t.join();
   int first = ICAMD_OK;
   for (uint32_t i = 0; i < n_images; ++i) {
     if (statuses) statuses[i] = local[i];
     if (first == ICAMD_OK && local[i] != ICAMD_OK) first = local[i];
   }
   if (first < 0)
-    for (const std::string &e : errors)
-      if (!e.empty()) { g_last_error = e; break; }
+    for (const WorkerError &e : errors)
+      if (!e.empty()) { set_last_error(e.text); break; }
   return first;
-}
+} ICAMD_ABI_CATCH
 
 // ---- CreateSolidImage / CopySubimage
 
@@ -907,7 +1052,7 @@ bool subimage_geometry(int compressor, int format, uint32_t ch, uint32_t cw, uin
 
 int icamd_create_solid_batch_device(int compressor, int format, uint32_t height, uint32_t width, uint32_t n_images,
                                     const uint8_t *colors, void *d_out, size_t dst_image_stride_bytes, size_t out_size_per_image,
-                                    void *hip_stream) {
+                                    void *hip_stream) try {
   const int comps = format_components(format);
   uint32_t probe[4];
   if (!colors || !d_out || comps == 0) return ICAMD_FALSE;
@@ -916,7 +1061,8 @@ int icamd_create_solid_batch_device(int compressor, int format, uint32_t height,
   const uint64_t n = (uint64_t)num_blocks4(height) * num_blocks4(width);
   if (out_size_per_image != n * bb) return ICAMD_FALSE;  // compressor4x4_helper.cc:34-41
   if ((reinterpret_cast<uintptr_t>(d_out) | dst_image_stride_bytes) % 4u) return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
-  if (n_images > 1 && dst_image_stride_bytes < out_size_per_image) return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
+  if ((n_images > 1 || dst_image_stride_bytes != 0) && dst_image_stride_bytes < out_size_per_image)
+    return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
   if (n >= (1ull << 32)) return fail(ICAMD_ERR_ARG, "more than 2^32 blocks in one image");
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
@@ -927,10 +1073,10 @@ int icamd_create_solid_batch_device(int compressor, int format, uint32_t height,
                                             reinterpret_cast<const uint32_t (*)[4]>(words.data()), n_images,
                                             static_cast<hipStream_t>(hip_stream)), "launch fill");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_create_solid_device(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color,
-                              void *d_out, size_t out_size, void *hip_stream) {
+                              void *d_out, size_t out_size, void *hip_stream) try {
   uint32_t w[4];
   const uint32_t bb = solid_block(compressor, format, color, w);
   if (bb == 0 || !d_out) return ICAMD_FALSE;
@@ -941,12 +1087,12 @@ int icamd_create_solid_device(int compressor, int format, uint32_t height, uint3
   if (rc != ICAMD_OK) return rc;
   ICAMD_HIP(icamd::launch_fill_blocks(d_out, n, (int)bb, w, static_cast<hipStream_t>(hip_stream)), "launch fill");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 // Host buffers in, host buffers out: replicating one block is byte shuffling with nothing to offload (a PCIe round
 // trip would be pure overhead), exactly what the reference does (helper.h:536-540).
 int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t width, const uint8_t *color, uint8_t *out,
-                       size_t out_size) {
+                       size_t out_size) try {
   uint32_t w[4];
   const uint32_t bb = solid_block(compressor, format, color, w);
   if (bb == 0 || !out) return ICAMD_FALSE;
@@ -954,12 +1100,12 @@ int icamd_create_solid(int compressor, int format, uint32_t height, uint32_t wid
   if (out_size != n * bb) return ICAMD_FALSE;
   for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * bb, w, bb);
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_copy_subimage_batch_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
                                      uint32_t n_images, const void *d_blocks, size_t src_image_stride_bytes, uint32_t start_row,
                                      uint32_t start_column, uint32_t height, uint32_t width, void *d_out,
-                                     size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) {
+                                     size_t dst_image_stride_bytes, size_t out_size_per_image, void *hip_stream) try {
   int bb;
   if (!d_blocks || !d_out ||
       !subimage_geometry(compressor, format, compressed_height, compressed_width, start_row, start_column, height, width, &bb))
@@ -968,8 +1114,9 @@ int icamd_copy_subimage_batch_device(int compressor, int format, uint32_t compre
   if (out_size_per_image != (size_t)rows * cols * (size_t)bb) return ICAMD_FALSE;
   if ((reinterpret_cast<uintptr_t>(d_blocks) | reinterpret_cast<uintptr_t>(d_out) | src_image_stride_bytes | dst_image_stride_bytes) % 4u)
     return fail(ICAMD_ERR_ARG, "block pointers and image strides must be 4-byte aligned");
-  if (n_images > 1 && (src_image_stride_bytes < (size_t)num_blocks4(compressed_height) * num_blocks4(compressed_width) * (size_t)bb ||
-                       dst_image_stride_bytes < out_size_per_image))
+  if (((n_images > 1 || src_image_stride_bytes != 0) &&
+       src_image_stride_bytes < (size_t)num_blocks4(compressed_height) * num_blocks4(compressed_width) * (size_t)bb) ||
+      ((n_images > 1 || dst_image_stride_bytes != 0) && dst_image_stride_bytes < out_size_per_image))
     return fail(ICAMD_ERR_ARG, "image stride smaller than an image");
   if (n_images == 0) return ICAMD_OK;
   int rc = require_device();
@@ -978,19 +1125,19 @@ int icamd_copy_subimage_batch_device(int compressor, int format, uint32_t compre
                                         rows, cols, d_out, static_cast<hipStream_t>(hip_stream), n_images,
                                         src_image_stride_bytes, dst_image_stride_bytes), "launch copy_subimage");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 int icamd_copy_subimage_device(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
                                const void *d_blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
-                               uint32_t width, void *d_out, size_t out_size, void *hip_stream) {
+                               uint32_t width, void *d_out, size_t out_size, void *hip_stream) try {
   return icamd_copy_subimage_batch_device(compressor, format, compressed_height, compressed_width, 1, d_blocks, 0, start_row,
                                           start_column, height, width, d_out, 0, out_size, hip_stream);
-}
+} ICAMD_ABI_CATCH
 
 // Host form: block-row memcpys like the reference (helper.h:583-589); nothing to offload.
 int icamd_copy_subimage(int compressor, int format, uint32_t compressed_height, uint32_t compressed_width,
                         const uint8_t *blocks, uint32_t start_row, uint32_t start_column, uint32_t height,
-                        uint32_t width, uint8_t *out, size_t out_size) {
+                        uint32_t width, uint8_t *out, size_t out_size) try {
   int bb;
   if (!blocks || !out ||
       !subimage_geometry(compressor, format, compressed_height, compressed_width, start_row, start_column, height, width, &bb))
@@ -1001,7 +1148,7 @@ int icamd_copy_subimage(int compressor, int format, uint32_t compressed_height, 
   for (uint32_t r = 0; r < rows; ++r)
     std::memcpy(out + (size_t)r * cols * bb, src + (size_t)r * src_cols * bb, (size_t)cols * bb);
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 // ---- diagnostics
 
@@ -1012,7 +1159,7 @@ uint32_t icamd_wall_clock_rate_khz(void) {
   return (uint32_t)khz;
 }
 
-int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stream) {
+int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stream) try {
   if (!d_out16 || reinterpret_cast<uintptr_t>(d_out16) % 8u) return fail(ICAMD_ERR_ARG, "clock probe: 8-byte aligned 16-byte buffer needed");
   int rc = require_device();
   if (rc != ICAMD_OK) return rc;
@@ -1023,7 +1170,7 @@ int icamd_clock_probe_device(void *d_out16, uint32_t duration_us, void *hip_stre
   const uint64_t ticks = (uint64_t)duration_us * khz / 1000u;
   ICAMD_HIP(icamd::launch_clock_probe(static_cast<uint64_t *>(d_out16), ticks, static_cast<hipStream_t>(hip_stream)), "launch clock probe");
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 // ---- multi-GPU from one process, device-resident
 
@@ -1031,9 +1178,10 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
                                       uint32_t width, uint32_t row_stride_bytes, uint32_t n_images,
                                       const void *const *d_srcs, void *const *d_dsts, const int *devices, int n_devices,
                                       int gather_device, void *d_gathered, size_t gathered_image_stride_bytes,
-                                      int *statuses) {
+                                      int *statuses) try {
   if (n_images == 0) return ICAMD_OK;
   if (!d_srcs || !devices || n_devices <= 0) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: null list");
+  if (n_devices > kMaxDeviceListEntries) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: device list longer than 256 entries");
   const bool gather = gather_device >= 0;
   if (!gather && !d_dsts) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: no output (d_dsts and no gather)");
   if (gather && !d_gathered) return fail(ICAMD_ERR_ARG, "icamd_encode_batch_sharded_device: gather without a buffer");
@@ -1050,16 +1198,21 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
   int prev_device = 0;
   (void)hipGetDevice(&prev_device);
   std::vector<int> local(n_images, ICAMD_OK);
-  std::vector<std::string> errors((size_t)n_devices);
+  std::vector<WorkerError> errors((size_t)n_devices);
   std::vector<std::thread> workers;
   workers.reserve((size_t)n_devices);
-  for (int d = 0; d < n_devices; ++d) {
-    workers.emplace_back([&, d]() {
+  int not_started_from = n_devices;  // list entries from here on have no worker (thread creation failed)
+  {
+  JoinAll join_on_every_path_out{workers};
+  for (int d = 0; d < n_devices && (uint32_t)d < n_images; ++d) {
+    try {
+    workers.emplace_back([&, d]() noexcept {
       const int dev = devices[d];
       auto fail_all = [&](int code, const char *what) {
-        for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) local[i] = code;
-        errors[(size_t)d] = what;
+        for (uint64_t i = (uint64_t)d; i < n_images; i += (uint64_t)n_devices) local[i] = code;
+        errors[(size_t)d].set(what);
       };
+      try {
       if (hipSetDevice(dev) != hipSuccess) return fail_all(ICAMD_ERR_HIP, "hipSetDevice failed");
       if (gather && dev != gather_device) {
         // direct xGMI copies into the gather buffer: without peer access hipMemcpyPeerAsync bounces through host memory.
@@ -1074,7 +1227,7 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
       std::unique_ptr<Staging> st = pool_take(dev);
       // this worker's images, in order
       std::vector<uint32_t> mine;
-      for (uint32_t i = (uint32_t)d; i < n_images; i += (uint32_t)n_devices) mine.push_back(i);
+      for (uint64_t i = (uint64_t)d; i < n_images; i += (uint64_t)n_devices) mine.push_back((uint32_t)i);
       auto slot_of = [&](uint32_t i) { return static_cast<uint8_t *>(d_gathered) + (size_t)i * gathered_image_stride_bytes; };
       // where image i is encoded to: its own buffer, its gather slot (images of the gather device), or scratch (nullptr here)
       auto target_of = [&](uint32_t i) -> uint8_t * {
@@ -1128,7 +1281,7 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
         if (!d_srcs[i0]) { local[i0] = ICAMD_FALSE; j += 1; continue; }
         if (!own && !gather) {  // nowhere to put this image's blocks
           local[i0] = ICAMD_ERR_ARG;
-          if (errors[(size_t)d].empty()) errors[(size_t)d] = "icamd_encode_batch_sharded_device: image without an output buffer";
+          if (errors[(size_t)d].empty()) errors[(size_t)d].set("icamd_encode_batch_sharded_device: image without an output buffer");
           j += 1;
           continue;
         }
@@ -1150,16 +1303,31 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
           }
         }
         for (size_t k = 0; k < len; ++k)
-          if (local[mine[j + k]] < 0 && errors[(size_t)d].empty()) errors[(size_t)d] = g_last_error;
+          if (local[mine[j + k]] < 0 && errors[(size_t)d].empty()) errors[(size_t)d].set(g_last_error);
         j += len;
       }
       icamd::pvrtc2_select_workspace(0);
       const hipError_t e1 = hipStreamSynchronize(st->stream), e2 = hipStreamSynchronize(st->stream2);
       if (e1 != hipSuccess || e2 != hipSuccess) fail_all(ICAMD_ERR_HIP, "stream synchronize failed");
       pool_give(std::move(st));
+      } catch (...) {
+        // what was enqueued may still be running on the worker's streams: this device's images all count as failed
+        const int code = abi_exception();
+        fail_all(code, g_last_error);
+        (void)hipDeviceSynchronize();
+      }
     });
+    } catch (...) {  // std::system_error from the thread's creation (or bad_alloc): the workers started so far finish
+      (void)abi_exception();
+      not_started_from = d;
+      break;
+    }
   }
-  for (std::thread &t : workers) t.join();
+  }  // all started workers joined
+  for (int d = not_started_from; d < n_devices; ++d) {
+    for (uint64_t i = (uint64_t)d; i < n_images; i += (uint64_t)n_devices) local[i] = ICAMD_ERR_ALLOC;
+    errors[(size_t)d].set("icamd_encode_batch_sharded_device: could not start a worker thread");
+  }
   (void)hipSetDevice(prev_device);
   int first = ICAMD_OK;
   for (uint32_t i = 0; i < n_images; ++i) {
@@ -1167,10 +1335,10 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
     if (first == ICAMD_OK && local[i] != ICAMD_OK) first = local[i];
   }
   if (first < 0)
-    for (const std::string &e : errors)
-      if (!e.empty()) { g_last_error = e; break; }
+    for (const WorkerError &e : errors)
+      if (!e.empty()) { set_last_error(e.text); break; }
   return first;
-}
+} ICAMD_ABI_CATCH
 
 // ---- container framing (extension; csrc/containers.h) ----
 size_t icamd_container_size(int container, int codec, uint32_t height, uint32_t width, uint32_t levels) {
@@ -1189,7 +1357,7 @@ size_t icamd_container_size(int container, int codec, uint32_t height, uint32_t 
 }
 
 int icamd_container_write(int container, int codec, uint32_t height, uint32_t width, uint32_t levels,
-                          const uint8_t *const *level_data, const size_t *level_sizes, uint8_t *out, size_t out_size) {
+                          const uint8_t *const *level_data, const size_t *level_sizes, uint8_t *out, size_t out_size) try {
   using namespace icamd;
   if (container < ICAMD_CONTAINER_DDS || container > ICAMD_CONTAINER_PVR) return fail(ICAMD_ERR_ARG, "unknown container");
   if (codec < ICAMD_DXT1 || codec > ICAMD_PVRTC2) return fail(ICAMD_ERR_ARG, "unknown codec");
@@ -1209,7 +1377,7 @@ int icamd_container_write(int container, int codec, uint32_t height, uint32_t wi
     p += level_sizes[l];
   }
   return ICAMD_OK;
-}
+} ICAMD_ABI_CATCH
 
 #pragma GCC visibility pop
 }  // extern "C"

@@ -149,8 +149,12 @@ struct TlsWorkspace {
       if (!w) continue;
       w->user_ptr = nullptr;  // the override was this thread's
       w->user_bytes = 0;
-      std::lock_guard<std::mutex> lock(g_ws_mutex);
-      g_ws_parked.push_back(w);  // no HIP call here
+      try {
+        std::lock_guard<std::mutex> lock(g_ws_mutex);
+        g_ws_parked.push_back(w);  // no HIP call here
+      } catch (...) {
+        // (the list could not grow: this workspace stays allocated until the process ends; a destructor must not throw)
+      }
     }
   }
 };
@@ -783,25 +787,47 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
 namespace {
 std::atomic<int> g_path_mode{-1};   // -1: not read yet; 0 auto, 1 always two kernels, 2 one pass wherever it is eligible
 std::atomic<int> g_path_strip{-2};  // -2: not read yet; -1 auto, else log2(blocks per strip) of the one-pass kernel
+// The environment is read ONCE, by whichever of the first launch and the first icamd_pvrtc2_tune comes first; a tune() then
+// stores over it, so a launch on another thread can no longer read the environment on top of a tune() call.
+std::once_flag g_path_env_once;
 void read_path_env() {
-  if (g_path_mode.load() >= 0) return;
-  const char *m = getenv("ICAMD_PVRTC2_PATH"), *k = getenv("ICAMD_PVRTC2_STRIP");
-  int mode = 0;
-  if (m && !strcmp(m, "two")) mode = 1;
-  else if (m && !strcmp(m, "one")) mode = 2;
-  g_path_strip.store(k && *k ? atoi(k) : -1);
-  g_path_mode.store(mode);
+  std::call_once(g_path_env_once, [] {
+    const char *m = getenv("ICAMD_PVRTC2_PATH"), *k = getenv("ICAMD_PVRTC2_STRIP");
+    int mode = 0;
+    if (m && !strcmp(m, "two")) mode = 1;
+    else if (m && !strcmp(m, "one")) mode = 2;
+    g_path_strip.store(k && *k ? atoi(k) : -1);
+    g_path_mode.store(mode);
+  });
+}
+// Compute units of a device (cached per ordinal): the time model below counts the workgroup slots of THIS device -- a
+// partitioned MI355X (CPX: 32 CUs per partition) or another part must not be modelled as 256 CUs.  The model's
+// time constants stay the MI355X's: a wrong choice costs time, never bytes -- both paths write identical blocks.
+uint32_t device_compute_units(int dev) {
+  static std::atomic<uint32_t> cached[64];
+  if (dev >= 0 && dev < 64) {
+    const uint32_t c = cached[dev].load();
+    if (c) return c;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  if (dev >= 0 && dev < 64) cached[dev].store((uint32_t)cus);
+  return (uint32_t)cus;
 }
 // Strip height of the one-pass kernel for n_images size^2 textures, or -1 where the morph + encode pair is the better choice.
 // Time model, fitted on an MI355X (profiles/r05_ab_pvrtc_onepass.log, within 5 % of every measured shape from 1 x 512^2 to
 // 16 x 4096^2): a workgroup of K-block strips takes 11 + 5.8 K us whatever its width (its waves walk K + 2 block rows at two
 // waves per SIMD), a CU holds 8 / waves-per-workgroup of them, a launch takes ceil(workgroups / slots) such rounds; the pair
 // takes 10 us + 52.6 us per million blocks.  forced >= 0: that strip height; always: the best strip height, no comparison.
-int onepass_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always) {
+int onepass_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always, uint32_t compute_units) {
   const uint32_t log2_bw = log2_size - 3u, log2_bh = log2_size - 2u;
   if (log2_bw < 6u || log2_bw > 9u) return -1;  // a workgroup is one block row wide: 64 ... 512 lanes
+  // (a forced strip may be as tall as the texture, log2(size / 4): one workgroup per texture -- tests and A/B runs use it)
   if (forced >= 0) return forced < 2 ? 2 : (forced > (int)log2_bh ? (int)log2_bh : forced);
-  const uint64_t slots = 256ull * (8u >> (log2_bw - 6u));
+  const uint64_t slots = (uint64_t)compute_units * (8u >> (log2_bw - 6u));
   int best = -1;
   double best_us = 0.0;
   for (int sb = 2; sb <= 6 && sb <= (int)log2_bh; ++sb) {
@@ -861,7 +887,9 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
   read_path_env();
   if (g_path_mode.load() != 1 && (uint64_t)(P.size / 8) * (P.size / 4) * P.n_images < (1ull << 31)) {
     const bool force = g_path_mode.load() == 2;  // (a strip height only counts together with mode 2)
-    const int sb = onepass_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int sb = onepass_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
     if (sb >= 0) return launch_pvrtc2_onepass(P, sb, stream);
   }
   const uint32_t bw = P.size / 8, bh = P.size / 4;
@@ -1104,13 +1132,13 @@ namespace {
 // figure: the same pixels per CU and block row --, a CU holds 16 / waves-per-workgroup of them; the pair takes 10 us + 1.87 us per
 // million pixels.  Below ~8 Mpixel per launch neither fills the chip and the pair's two short kernels are as fast or faster
 // (1 x 2048^2: 15 vs 21 us), so it keeps those.
-int onepass4_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always) {
+int onepass4_log2_strip(uint32_t log2_size, uint64_t n_images, int forced, bool always, uint32_t compute_units) {
   const uint32_t log2_bw = log2_size - 2u;  // blocks per row = lanes per workgroup
   if (log2_bw < 6u || log2_bw > 10u) return -1;
   if (forced >= 0) return forced < 1 ? 1 : (forced > (int)log2_bw ? (int)log2_bw : forced);
   const uint64_t pixels = n_images << (2u * log2_size);
   if (!always && pixels < (8ull << 20)) return -1;
-  const uint64_t slots = 256ull * (16u >> (log2_bw - 6u));
+  const uint64_t slots = (uint64_t)compute_units * (16u >> (log2_bw - 6u));
   int best = -1;
   double best_us = 0.0;
   for (int sb = 2; sb <= 6 && sb <= (int)log2_bw; ++sb) {
@@ -1154,7 +1182,9 @@ hipError_t launch_pvrtc4(const PvrtcParams &P, hipStream_t stream) {
   read_path_env();
   if (g_path_mode.load() != 1 && (uint64_t)(P.size / 4) * (P.size / 4) * P.n_images < (1ull << 31)) {
     const bool force = g_path_mode.load() == 2;
-    const int sb = onepass4_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int sb = onepass4_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
     if (sb >= 0) return launch_pvrtc4_onepass(P, sb, stream);
   }
   const uint64_t bpi = (uint64_t)(P.size / 4) * (P.size / 4);

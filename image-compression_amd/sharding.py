@@ -112,13 +112,44 @@ def alloc_gather_buffers(local, counts, rank, dst=0):
     return [torch.empty((c,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device) for c in counts]
 
 
-def gather_to_root(local, bufs, counts, rank, dst=0, group=None, host_staged=False):
+def make_rccl_gather(pkg, rank, world, device):
+    """The library's own communicator for gather_to_root(..., rccl=...): rank 0's ncclUniqueId goes to the others through the
+    default process group (a 128-byte broadcast: on the device with the nccl backend, on the host with gloo)."""
+    on_device = dist.get_backend() == "nccl"
+
+    def broadcast_bytes(raw):
+        t = torch.zeros(pkg.RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8)
+        if raw is not None:
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+        if on_device:
+            t = t.to(device)
+        if world > 1 or _force_collectives():
+            dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+    return pkg.RcclGather(rank, world, broadcast_bytes)
+
+
+def gather_to_root(local, bufs, counts, rank, dst=0, group=None, host_staged=False, rccl=None):
     """Gathers per-rank compressed slabs (rank r holds counts[r] textures' worth of blocks) into `bufs` on rank `dst`
     (ranks of `group`).  Enqueued on the CURRENT stream and not synchronised, so the caller can run it on a side
-    stream underneath the next batch's encode.  Equal counts: one dist.gather (RCCL: grouped send/recv over the xGMI
-    links, every peer writes its own slab of rank 0's HBM).  Unequal counts (n_textures % world != 0): batched
+    stream underneath the next batch's encode.
+    rccl: an `RcclGather` (make_rccl_gather) -- the LIBRARY's collective, icamd_gather_blocks_rccl: one grouped ncclSend /
+    ncclRecv exchange, equal or unequal counts alike, every peer writing its own slab of rank dst's HBM over its own xGMI link.
+    Without it, torch.distributed: equal counts one dist.gather, unequal counts (n_textures % world != 0) batched
     point-to-point.  host_staged: the gloo debugging path (device tensors staged through host memory)."""
     world = len(counts)
+    if rccl is not None and not host_staged and (world > 1 or _force_collectives()):
+        # byte counts: root reads every rank's from its receive buffers (the C entry point only looks at a sender's own count
+        # on the sending side), a sender states its own
+        if rank == dst:
+            counts_bytes = [b.numel() * b.element_size() for b in bufs]
+            if counts_bytes[rank] != local.numel() * local.element_size():
+                raise ValueError("gather_to_root: root's own buffer does not have the size of its local output")
+        else:
+            counts_bytes = [0] * world
+            counts_bytes[rank] = local.numel() * local.element_size()
+        rccl.gather(local.contiguous().view(-1).view(torch.uint8), bufs if rank == dst else None, counts_bytes, root=dst)
+        return
     if world == 1 and not _force_collectives():
         bufs[0].copy_(local)
         return

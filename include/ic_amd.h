@@ -117,7 +117,8 @@ int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes);
  * pvrtc_compressor.cc:586-597 in ONE read of the pixels, no scratch memory -- such launches can be captured into a HIP graph
  * without a caller-owned workspace); everything else takes the morph + encode pair.  mode 0 = automatic (default; also the
  * value of the environment variable ICAMD_PVRTC2_PATH=auto|two|one read at the first launch), 1 = always the pair, 2 = one pass
- * wherever eligible; log2_strip < 0 = automatic strip height (blocks per lane) of the one-pass kernel, else 2 ... 6.
+ * wherever eligible; log2_strip < 0 = automatic strip height (blocks per lane) of the one-pass kernel (2 ... 6), else that height, clamped to
+ * 2 ... log2(size / 4) (the tallest strip is the whole texture: one workgroup per texture).
  * Process-wide.  Returns ICAMD_OK, or ICAMD_ERR_ARG for a mode outside 0 ... 2. */
 int icamd_pvrtc2_tune(int mode, int log2_strip);
 
@@ -283,6 +284,43 @@ int icamd_encode_batch_sharded_device(int codec, int etc_strategy, int src_compo
                                       const void *const *d_srcs, void *const *d_dsts, const int *devices, int n_devices,
                                       int gather_device, void *d_gathered, size_t gathered_image_stride_bytes,
                                       int *statuses);
+
+/* ---- multi-GPU, ONE PROCESS PER GPU: the gather of the compressed output over RCCL ("Collective" column) ----
+ * BASELINE.json's north star: "large texture batches shard across the 8 GPUs of one node as independent image slabs ...
+ * RCCL over xGMI only to gather the compressed output".  Encoding needs no exchange (icamd_encode_device on every rank's own
+ * textures, or its block-row slab / PVRTC region of one image: helper.h:202-214 makes a slab's blocks ONE contiguous byte
+ * range of the final buffer); what a C / C++ caller of the drop-in classes that runs one process per GPU still needs is the
+ * collective that brings the ranks' byte ranges together on one rank -- this entry point.  The reference has nothing of the
+ * kind (it is a single-threaded CPU library, public/compressor.h:48-138): there is no interface to cite, only the layout rule.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1 -- the copy already loaded into the process if there is one, e.g.
+ * PyTorch's), so libic_amd.so itself does not depend on it and every other entry point works without it.
+ *
+ * icamd_rccl_available       1 if librccl could be bound, else 0 (and icamd_last_error() says why).
+ * icamd_rccl_get_unique_id   ncclGetUniqueId into id[ICAMD_RCCL_UNIQUE_ID_BYTES]; call on ONE rank and hand the bytes to the
+ *                            others by any means (MPI_Bcast, a file, a socket, torch.distributed's store).
+ * icamd_rccl_comm_init       ncclCommInitRank on the CURRENT HIP device; *comm is an ncclComm_t.  Collective: every rank
+ *                            calls it with the same id and world.  A communicator the caller made with its own RCCL calls
+ *                            (same librccl) is equally accepted by icamd_gather_blocks_rccl.
+ * icamd_rccl_comm_destroy    ncclCommDestroy.
+ * icamd_gather_blocks_rccl   rank r contributes counts_bytes[r] bytes at d_local (device memory of its own GPU); on rank
+ *                            `root` they land at d_root_buffer + root_offsets_bytes[r] (NULL = the prefix sums of
+ *                            counts_bytes: the ranks' ranges back to back, which is the final block stream when the ranks
+ *                            hold consecutive slabs / texture ranges).  Unequal and zero counts are fine.  ONE grouped
+ *                            ncclSend / ncclRecv exchange (ncclGroupStart ... ncclGroupEnd, ncclUint8): every peer writes
+ *                            its own range of root's HBM over its own xGMI link; root's own range is a device-to-device
+ *                            copy on the same stream (skipped when d_local already is its slot).  Enqueued on hip_stream,
+ *                            not synchronised: run it on a second stream underneath the next batch's encode.  d_root_buffer
+ *                            and root_offsets_bytes are only read on root.  Every rank passes the same counts.
+ * Status: ICAMD_OK; ICAMD_ERR_ARG (bad rank / world / root, null pointers where bytes are due); ICAMD_ERR_NO_DEVICE when
+ * librccl cannot be bound; ICAMD_ERR_HIP with RCCL's own error text for a failing RCCL or HIP call. */
+#define ICAMD_RCCL_UNIQUE_ID_BYTES 128
+int icamd_rccl_available(void);
+int icamd_rccl_get_unique_id(void *id);
+int icamd_rccl_comm_init(void **comm, int world, int rank, const void *id);
+int icamd_rccl_comm_destroy(void *comm);
+int icamd_gather_blocks_rccl(void *comm, int rank, int world, int root, const size_t *counts_bytes, const void *d_local,
+                             void *d_root_buffer, const size_t *root_offsets_bytes, void *hip_stream);
 
 /* ---- container framing (EXTENSION: SURVEY.md 8(f) row 4, tail) ----
  * The reference ends at the raw block stream (compressed_image.h:52-66); it has no file-container code, so there is

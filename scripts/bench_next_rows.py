@@ -11,6 +11,25 @@ pkg = ic_amd_loader.load_package()
 import ic_testlib as T
 L = pkg.lib()
 BAD = []
+# r06: `--json PATH` additionally writes every leg as an object (bench.py's `next_rows` field reads it); `--core` runs only the legs
+# VERDICT r05 item 5 puts a bar on (decoders, Downsample, transcode) -- what bench.py's default line can afford
+JSON_PATH = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+CORE = "--core" in sys.argv
+LEGS = []
+_print = print
+
+def print(*a, **k):  # every result line is "<leg name> ... <GB/s> GB/s ... (<ms> ms ...) parity: ..."; recorded as it is printed
+    _print(*a, **k)
+    import re as _re
+    line = " ".join(str(x) for x in a)
+    m_g = _re.search(r"([0-9.]+) GB/s", line)
+    m_t = _re.search(r"\(([0-9.]+) ms", line)
+    if m_g and m_t and "parity:" in line:
+        name = _re.split(r"\s+[0-9.]+ (?:Mpix/s|GB/s)", line)[0].strip()
+        name = _re.sub(r"\s+", " ", name)
+        LEGS.append({"leg": name, "algorithmic_GBps": float(m_g.group(1)), "frac": round(float(m_g.group(1)) / 8000.0, 4),
+                     "ms_per_call": float(m_t.group(1)), "parity": "bit-exact" if "bit-exact" in line else "MISMATCH",
+                     "one_launch": "one call per image" not in line})
 
 def parity(what, got, want):
     """got: device tensor (image 0 of the timed call's output), want: the oracle's bytes."""
@@ -91,6 +110,21 @@ for name, codec, comps, bb in [("dxt1", 0, 3, 8), ("dxt5", 1, 4, 16), ("etc1", 2
         print("downsample %-5s batched%s %8.0f Mpix/s source  %6.0f GB/s algorithmic (%.3f ms per %d images, one launch)  %s" % (
             name, " strategy %d" % strat if codec == 2 else "", px / t / 1e6, (blocks.numel() + dn.numel()) / t / 1e9, t * 1e3, batch,
             parity("downsample batched %s s%d" % (name, strat), dn[0], T.oracle_downsample(compressor, fmt, b0, n, n, strat))))
+    if CORE:
+        if codec == 0:
+            work = blocks.clone()
+            def tr():
+                rc = L.icamd_transcode_dxt1_to_etc1_device(ctypes.c_void_p(work.data_ptr()), work.numel(), sh)
+                assert rc == 0
+            t = timeit(tr, 10)
+            work.copy_(blocks)
+            tr()
+            print("transcode dxt1->etc1 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms)  %s" % (
+                px / t / 1e6, 2 * work.numel() / t / 1e9, t * 1e3, parity("transcode", work[0], T.oracle_transcode(b0))))
+            del work
+        del out, dn, blocks
+        torch.cuda.empty_cache()
+        continue
     # Pad (helper.h:393-477) to a grid two block rows / columns larger: a copy plus one re-encoded / bit-edited border
     ph = pw = n + 8
     pout = torch.empty((batch, ((ph + 3) // 4) * ((pw + 3) // 4) * bb), dtype=torch.uint8, device=dev)
@@ -180,6 +214,16 @@ t = timeit(dec_pvrtc)
 print("decode pvrtc %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s (extension: the reference has no PVRTC decoder)" % (
     batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
     parity("decode pvrtc", out[0], T.oracle_decode(3, blocks[0].cpu().numpy().tobytes(), n, n).tobytes())))
+def finish():
+    print("next rows: %s" % ("ALL LEGS bit-exact vs oracle at the timed shape" if not BAD else "MISMATCH in: " + ", ".join(BAD)))
+    if JSON_PATH:
+        import json
+        with open(JSON_PATH, "w") as f:
+            json.dump({"legs": LEGS, "all_bit_exact": not BAD, "shape": "%d x %d^2, device-resident, steady state (0.25 s of untimed calls first)" % (batch, n),
+                       "library": L.icamd_version().decode()}, f)
+    sys.exit(1 if BAD else 0)
+if CORE:
+    finish()
 # PVRTC 4 bpp decoder (r05: the decoder of the 4 bpp extension encoder; parity unpinned like it)
 del blocks
 src = torch.randint(0, 256, (batch, n, n, 4), dtype=torch.uint8, device=dev, generator=g)
@@ -194,5 +238,4 @@ t = timeit(dec_pvrtc4)
 print("decode pvrtc4 %8.0f Mpix/s  %6.0f GB/s algorithmic (%.3f ms per %d x %d^2)  %s (extension of an extension: no reference for the format)" % (
     batch * n * n / t / 1e6, (blocks.numel() + out.numel()) / t / 1e9, t * 1e3, batch, n,
     parity("decode pvrtc4", out[0], T.oracle_decode(4, blocks[0].cpu().numpy().tobytes(), n, n).tobytes())))
-print("next rows: %s" % ("ALL LEGS bit-exact vs oracle at the timed shape" if not BAD else "MISMATCH in: " + ", ".join(BAD)))
-sys.exit(1 if BAD else 0)
+finish()

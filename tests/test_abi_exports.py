@@ -109,3 +109,36 @@ def test_host_forms_of_create_solid_and_copy_subimage_match_oracle_and_reference
                 assert got == T.oracle_copy_subimage(compressor, fmt, blocks, ch, cw, r, c, sh, sw), (compressor, fmt, r, c, sh, sw)
             else:
                 assert got is None  # start + extent wraps 32 bits: refused here (the reference would read out of bounds)
+
+
+def test_batch_entry_points_refuse_absurd_device_lists_before_starting_a_thread(pkg):
+    """one worker thread per device-list entry must not be something a caller can ask 10 000 of; the check
+    needs no device (it comes before anything is allocated or started)."""
+    lib = pkg.lib()
+    n = 10000
+    devs = (ctypes.c_int * n)(*([0] * n))
+    one = (ctypes.c_void_p * 1)(0)
+    st = (ctypes.c_int * 1)(5)
+    rc = lib.icamd_compress_batch(T.DXTC, 2, T.RGB, 8, 8, 0, 1, one, one, 32, devs, n, st)
+    assert rc == -4 and b"device list" in lib.icamd_last_error()
+    rc = lib.icamd_encode_batch_sharded_device(pkg.DXT1, 2, 3, 0, 8, 8, 24, 1, one, one, devs, n, -1, None, 0, st)
+    assert rc == -4 and b"device list" in lib.icamd_last_error()
+    # a long error text is cut to the fixed buffer, never allocated for (icamd_last_error() is a plain thread-local array)
+    assert len(lib.icamd_last_error()) < 256
+
+
+def test_rccl_entry_points_validate_before_they_need_rccl_or_a_device(pkg):
+    """The C gather's argument checks (include/ic_amd.h) answer without a GPU; binding librccl is reported by
+    icamd_rccl_available, never by an exception or an abort."""
+    lib = pkg.lib()
+    assert lib.icamd_rccl_available() in (0, 1)
+    counts = (ctypes.c_size_t * 2)(8, 8)
+    assert lib.icamd_gather_blocks_rccl(None, 0, 2, 0, counts, None, None, None, None) == -4
+    fake = ctypes.c_void_p(1)  # never dereferenced: the checks below come first
+    assert lib.icamd_gather_blocks_rccl(fake, 2, 2, 0, counts, None, None, None, None) == -4
+    assert lib.icamd_gather_blocks_rccl(fake, 0, 2, 5, counts, None, None, None, None) == -4
+    assert lib.icamd_gather_blocks_rccl(fake, 1, 2, 0, counts, None, None, None, None) == -4   # bytes to send, no d_local
+    assert lib.icamd_gather_blocks_rccl(fake, 0, 2, 0, None, None, None, None, None) == -4
+    assert lib.icamd_rccl_get_unique_id(None) == -4
+    assert lib.icamd_rccl_comm_init(None, 1, 0, None) == -4
+    assert lib.icamd_rccl_comm_destroy(None) == 0

@@ -1103,10 +1103,13 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
         assert leg["distinct_images_rotated"] >= 5 and leg["distinct_source_MiB_per_rank"] >= 320, (name, leg)
     for name, leg in d["configs"].items():  # r05: every leg says at which clock and VALU issue fraction it ran
         assert leg["roofline"]["effective_clock_MHz"] > 500, (name, leg["roofline"])
-        assert 0 < leg["roofline"]["valu_frac"] < 1.2, (name, leg["roofline"])  # (r05: from SQ_INSTS_VALU counted in the run)
+        # (r05: from SQ_INSTS_VALU counted in the run; r06: clock and kernel time of the SAME launches -- a fraction above 1 is
+        # not a measurement)
+        assert 0 < leg["roofline"]["valu_frac"] <= 1.0, (name, leg["roofline"])
+        assert leg["roofline"]["clock_window_kernel_ms"] > 0
         assert leg["roofline"]["valu_profile"].startswith("measured in this run"), (name, leg["roofline"])
     other = d["configs"]["c4"]["other_contents"]
-    assert sorted(other) == ["flat", "smooth"] and all(v["parity"].startswith("bit-exact") and v["valu_frac"] for v in other.values())
+    assert sorted(other) == ["flat", "smooth"] and all(v["parity"].startswith("bit-exact") and 0 < v["valu_frac"] <= 1.0 for v in other.values())
     assert d["link_probe"] is None and "value_with_gather_ceiling" in d["scaling_headline"]
     d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--shard", "slab", "--workload", "dxt5_rgba8",
                     "--size", "8192", "--steps", "3"])
@@ -1167,12 +1170,17 @@ def test_rccl_code_path_executes_with_a_single_rank(pkg):
                         "--master-addr", "127.0.0.1", "--master-port", "29643",
                         os.path.join(T.ROOT, "tests", "nccl_worker.py")], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "NCCL_WORKER_OK" in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
-    d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--steps", "4", "--warmup", "1",
-                    "--workload", "dxt1_rgba8", "--size", "1024", "--batch", "3", "--no-cpu-baseline", "--no-host-api",
-                    "--no-sustained", "--no-single-image", "--precondition-seconds", "0"])
-    assert d["n_gpus"] == 1 and d["parity"].startswith("bit-exact")
-    assert d["value_with_gather"] > 0 and d["gather_ms"] > 0 and d["rank0_copy_matches"] is True
-    assert "backend nccl" in d["gather"]
+    for impl in ("torch", "c"):  # r06: the gather legs default to the library's own collective (icamd_gather_blocks_rccl)
+        d = _run_bench(["--gpus", "1", "--force-distributed", "--backend", "nccl", "--steps", "4", "--warmup", "1",
+                        "--workload", "dxt1_rgba8", "--size", "1024", "--batch", "3", "--no-cpu-baseline", "--no-host-api",
+                        "--no-sustained", "--no-single-image", "--precondition-seconds", "0"]
+                       + (["--gather-impl", "torch"] if impl == "torch" else []))
+        assert d["n_gpus"] == 1 and d["parity"].startswith("bit-exact")
+        assert d["value_with_gather"] > 0 and d["gather_ms"] > 0 and d["rank0_copy_matches"] is True
+        if impl == "torch":
+            assert "backend nccl" in d["gather"] and "--gather-impl torch" in d["gather_impl"]
+        else:
+            assert "icamd_gather_blocks_rccl" in d["gather"] and "icamd_gather_blocks_rccl" in d["gather_impl"], d["gather_impl"]
 
 
 def test_every_inter_gpu_path_on_a_multi_gpu_box(pkg):
