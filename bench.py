@@ -555,7 +555,8 @@ def single_image_leg(torch, pkg, codec, comps, src, size, batch, strategy, strea
     }
 
 
-def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, kernel_ms, clock_mhz, preset=None, live_insts=None):
+def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, kernel_ms, clock_mhz, preset=None, live_insts=None,
+                  live_cycles=None):
     """Integer-VALU issue fraction of the sustained run, from measured quantities only:
       executed VALU wave-instructions per kernel  -- SQ_INSTS_VALU of the committed PMC profile of EXACTLY this workload /
                                                     content / ETC strategy (profiles/valu_insts.json);
@@ -597,6 +598,21 @@ def valu_fraction(workload, content, etc_strategy, codec, pixels_per_launch, ker
     else:
         clocks = vi["valu_wave_insts_per_Mpixel"] * mpix * 4.0
     mhz = clock_mhz or 2400.0
+    if live_insts and live_cycles and sorted(live_cycles) == sorted(live_insts):
+        # r06: numerator AND denominator from ONE profiled pass over the same launches -- executed VALU
+        # wave-instructions (SQ_INSTS_VALU) x model issue clocks over 1 024 SIMDs x the shader cycles those launches took
+        # (GRBM_GUI_ACTIVE / 8 XCDs): no clock probe, no kernel time of another run, nothing that can drift apart.
+        # simd_cycles_per_valu_inst is the model-free part: what the SIMDs spent per VALU instruction (profiles/r06_valu_counters.txt:
+        # 3.8 - 4.0 for the VALU-bound kernels at four waves per SIMD).
+        cyc = sum(live_cycles.values())
+        return {"valu_frac": round(clocks / (1024.0 * cyc), 3),
+                "simd_cycles_per_valu_inst": round(1024.0 * cyc / sum(live_insts.values()), 3),
+                "model_issue_clk_per_valu_inst": round(clocks / sum(live_insts.values()), 3),
+                "valu_wave_insts_per_block": vi.get("valu_wave_insts_per_block_lane"),
+                "valu_profile": vi.get("profile") + "; shader cycles of the same launches from GRBM_GUI_ACTIVE / 8 in the same pass",
+                "valu_kernels": detail, "valu_clock_MHz": "not needed: cycles counted (GRBM_GUI_ACTIVE)",
+                "valu_frac_note": "executed VALU wave-instructions x model issue clocks (4; 2 for the add / logic / right-shift / mov "
+                                  "ops, static mix of the kernel) / (1024 SIMDs x shader cycles of the same launches)"}
     return {"valu_frac": round(clocks / (1024 * mhz * 1e6) / (kernel_ms * 1e-3), 3),
             "valu_wave_insts_per_block": vi.get("valu_wave_insts_per_block_lane"),
             "valu_profile": vi.get("profile"), "valu_kernels": detail,
@@ -806,6 +822,7 @@ def timed_steps(ctx, step, steps, warmup, precondition_seconds=0.0, stream=None)
     return elapsed, kernel_ms
 
 
+LIVE_GUI_CYCLES = {}    # the same key -> {kernel: shader cycles per launch (GRBM_GUI_ACTIVE / 8 XCDs)} of the SAME profiled launches
 LIVE_VALU_INSTS = {}    # (workload, size, batch, content, etc_strategy) -> {kernel: SQ_INSTS_VALU per launch}, filled by live_traffic()
 _LIVE_TRAFFIC_OFF = []  # set to [reason] by the first failed live measurement: the remaining legs go straight to the committed profile
 
@@ -831,7 +848,10 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="icamd_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+            # (r06: the third pass also reads GRBM_GUI_ACTIVE -- another block, same pass: the shader cycles of the very launches
+            # whose instructions are counted, summed over the 8 XCDs -- so that valu_frac needs neither a clock nor a time)
+            ctrs = [ctr, "GRBM_GUI_ACTIVE"] if ctr == "SQ_INSTS_VALU" else [ctr]
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
                    os.path.abspath(__file__), "--traffic-child", "--workload", workload, "--size", str(size), "--batch", str(batch),
                    "--content", content, "--etc-strategy", str(etc_strategy)]
             # own process group: a pass that overruns is killed WITH the child it started (rocprofv3 is a wrapper)
@@ -842,18 +862,22 @@ def live_traffic(workload, size, batch, content, etc_strategy, timeout_s=75):
                 os.killpg(r.pid, signal.SIGKILL)
                 r.wait()
                 raise
-            per_kernel = {}
+            per_kernel, gui = {}, {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         if row["Kernel_Name"].startswith("icamd_") and row["Counter_Name"] == ctr:
                             per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                        elif row["Kernel_Name"].startswith("icamd_") and row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                            gui.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
             if r.returncode != 0 or not per_kernel:
                 _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass failed (rc %s)" % (ctr, r.returncode))
                 return None, _LIVE_TRAFFIC_OFF[0]
             kib[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
             if ctr == "SQ_INSTS_VALU":  # executed VALU wave-instructions per launch, per kernel: valu_fraction()'s input
                 LIVE_VALU_INSTS[(workload, size, batch, content, etc_strategy)] = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+                if gui and sorted(gui) == sorted(per_kernel):
+                    LIVE_GUI_CYCLES[(workload, size, batch, content, etc_strategy)] = {k: sum(v) / len(v) / 8.0 for k, v in gui.items()}
         except Exception as e:  # a diagnostic: never fatal, and never paid for twice
             _LIVE_TRAFFIC_OFF.append("rocprofv3 --pmc %s pass: %s: %s" % (ctr, type(e).__name__, str(e)[:200]))
             return None, _LIVE_TRAFFIC_OFF[0]
@@ -947,9 +971,11 @@ def preset_leg(ctx, pkg, sharding, name, steps, content="noise", verify=True, ga
         res["roofline"]["clock_window_kernel_ms"] = None if window_ms is None else round(window_ms, 4)
         # valu_frac: instructions x issue clocks over (SIMDs x clock x time) with clock AND time of the same launches
         vf = valu_fraction(cfg["workload"], content, strategy, codec, px_rank, window_ms if (mhz and window_ms) else kernel_ms, mhz,
-                           preset=name, live_insts=LIVE_VALU_INSTS.get((cfg["workload"], size, batch, content, strategy)))
+                           preset=name, live_insts=LIVE_VALU_INSTS.get((cfg["workload"], size, batch, content, strategy)),
+                           live_cycles=LIVE_GUI_CYCLES.get((cfg["workload"], size, batch, content, strategy)))
         if vf:
-            res["roofline"].update({k: vf[k] for k in ("valu_frac", "valu_wave_insts_per_block", "valu_profile", "valu_clock_MHz")})
+            res["roofline"].update({k: vf[k] for k in ("valu_frac", "valu_wave_insts_per_block", "valu_profile", "valu_clock_MHz",
+                                                       "simd_cycles_per_valu_inst", "model_issue_clk_per_valu_inst") if k in vf})
         if verify:
             import ic_testlib as T
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8
@@ -1475,7 +1501,8 @@ def main():
                     result["roofline"]["effective_clock_MHz"] = mhz
                 vf = valu_fraction(args.workload, args.content, args.etc_strategy, codec, pixels_per_step_rank,
                                    sus["median_ms_last_20pct"], mhz,
-                                   live_insts=LIVE_VALU_INSTS.get((args.workload, size, batch, args.content, args.etc_strategy)))
+                                   live_insts=LIVE_VALU_INSTS.get((args.workload, size, batch, args.content, args.etc_strategy)),
+                                   live_cycles=LIVE_GUI_CYCLES.get((args.workload, size, batch, args.content, args.etc_strategy)))
                 if vf:
                     result["roofline"].update(vf)
             except Exception as e:
@@ -1518,7 +1545,8 @@ def main():
                             other[content] = {k: r.get(k) for k in ("value", "unit", "ms_per_step", "steps", "parity", "data")}
                             rf = r.get("roofline") or {}
                             other[content].update({k: rf.get(k) for k in ("frac", "valu_frac", "effective_clock_MHz", "kernel_ms", "clock_window_kernel_ms",
-                                                                           "valu_wave_insts_per_block", "valu_profile", "traffic")})
+                                                                           "valu_wave_insts_per_block", "valu_profile", "traffic",
+                                                                           "simd_cycles_per_valu_inst")})
                         except Exception as e:
                             other[content] = {"error": "%s: %s" % (type(e).__name__, e)}
                     configs[name]["other_contents"] = other

@@ -86,15 +86,67 @@ __device__ __forceinline__ Out8 etc1_encode_classified(const uint32_t px[16], bo
 #endif
 // (kHeuristic has no content-dependent path: it keeps the four-wave workgroups, whose dispatch costs a quarter as much)
 constexpr bool etc1_wave_workgroups(int strategy) { return ICAMD_ETC1_WAVE_WORKGROUPS != 0 && strategy != 3; }
-template <int STRATEGY>
+// ICAMD_ETC1_XCD_COLUMNS (r06, 3-byte sources): which tile column a workgroup takes.  A wave of a 16 x 16-block RGB888 tile reads
+// 192-byte row segments: tiles 2 k and 2 k + 1 together cover three 128-byte lines and SHARE the middle one.  Workgroups are dealt
+// to the eight XCDs round-robin in launch order (x fastest), each XCD with an L2 of its own -- with the plain mapping (tile column
+// = blockIdx.x >> 2, wave = blockIdx.x & 3) the two tiles of such a pair ALWAYS sit on different XCDs (their workgroup indices
+// differ by 4), so every shared line crosses the fabric twice: FETCH_SIZE 1.29 x the algorithmic bytes in every round's profile.
+// Mode 2 (default): XCD r = blockIdx.x & 7 takes wave r & 3 of the tile PAIRS with parity r >> 2, q = blockIdx.x >> 3 counting its
+// tiles along the row -- the two tiles of a pair run the same wave on the SAME XCD one dispatch apart, and the second reader finds
+// the line in L2: counter traffic 1.286 -> 1.009 x (kHeuristic, four-wave workgroups: 1.286 -> 1.14, and + 1.7 % Mpixels/s), same
+// tiles, same waves, same lanes, same bytes out, 4 scalar instructions, time unchanged on every content.
+// Modes 1 (the left / right HALF of a tile row per XCD group) and 4 (QUADS of tiles in the order A B B A) reach the same traffic
+// and LOSE 8 % on smooth content (c4: 182.5 -> 167.5 Gpixel/s): the partition is static, the search's cost follows the image, and a
+// gradient along the row loads the XCD groups unequally -- the finest grouping that still keeps a pair together is the one to
+// take (profiles/r06_ab_etc1_xcd.log).  0 = the plain mapping.
+#ifndef ICAMD_ETC1_XCD_COLUMNS
+#define ICAMD_ETC1_XCD_COLUMNS 2
+#endif
+// blockIdx.x -> (tile column, wave of the tile) for one-wave workgroups; -> tile column for four-wave workgroups (wave unused)
+template <int COMPS, bool WAVE_WORKGROUPS>
+__device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t &tile_col, uint32_t &wave) {
+  const uint32_t bx = blockIdx.x, gx = gridDim.x;
+  constexpr uint32_t kMode = ICAMD_ETC1_XCD_COLUMNS;
+  if (WAVE_WORKGROUPS) {
+    tile_col = bx >> 2;
+    wave = bx & 3u;
+    if (kMode == 0u || COMPS != 3) return;
+    // XCD r = bx & 7 (workgroups are dealt round-robin in launch order, x fastest, and gx is a multiple of 8 below): g = r >> 2
+    // picks the group of tile columns, q = bx >> 3 counts the group's tiles along the row; tiles per row = gx / 4
+    const uint32_t r = bx & 7u, g = r >> 2, q = bx >> 3;
+    if (kMode == 1u && (gx & 7u) == 0u) {
+      wave = r & 3u;
+      tile_col = g * (gx >> 3) + q;
+    } else if (kMode == 2u && (gx & 15u) == 0u) {
+      wave = r & 3u;
+      tile_col = 4u * (q >> 1) + 2u * g + (q & 1u);
+    } else if (kMode == 4u && (gx & 31u) == 0u) {
+      const uint32_t m = q >> 2;
+      wave = r & 3u;
+      tile_col = 8u * m + 4u * (g ^ (m & 1u)) + (q & 3u);
+    }
+  } else {
+    // four-wave workgroups (kHeuristic): XCD r = bx & 7 takes every 8th RUN of tiles; runs of gx / 8 (mode 1), 2 or 4 tiles
+    tile_col = bx;
+    wave = 0u;
+    if (kMode == 0u || COMPS != 3) return;
+    const uint32_t r = bx & 7u, q = bx >> 3;
+    if (kMode == 1u && (gx & 7u) == 0u) tile_col = r * (gx >> 3) + q;
+    else if (kMode == 2u && (gx & 15u) == 0u) tile_col = 16u * (q >> 1) + 2u * r + (q & 1u);
+    else if (kMode == 4u && (gx & 31u) == 0u) tile_col = 32u * (q >> 2) + 4u * r + (q & 3u);
+  }
+}
+template <int STRATEGY, int COMPS>
 __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
   if (etc1_wave_workgroups(STRATEGY)) {
   TileCoord t;
   const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
-  const uint32_t vt = threadIdx.x + 64u * (blockIdx.x & 3u);
+  uint32_t tile_col, wave;
+  etc1_tile_of_workgroup<COMPS, true>(tile_col, wave);
+  const uint32_t vt = threadIdx.x + 64u * wave;
   t.lx = vt & (cols - 1u);
   t.ly = vt >> P.log2_tile_cols;
-  t.bcol0 = (blockIdx.x >> 2) * cols;
+  t.bcol0 = tile_col * cols;
   t.brow0 = (blockIdx.y + P.tile_row0) * rows;
   t.bcol = t.bcol0 + t.lx;
   t.brow = t.brow0 + t.ly;
@@ -104,7 +156,9 @@ __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
   t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
   return t;
   }
-  TileCoord t = locate_tile<false>(P);
+  uint32_t tile_col, wave;
+  etc1_tile_of_workgroup<COMPS, false>(tile_col, wave);
+  TileCoord t = locate_tile<false>(P, tile_col);
   if (ICAMD_ETC1_WAVE_8X8 && P.log2_tile_cols == 4u) {
     const uint32_t tid = threadIdx.x;
     t.lx = (tid & 7u) + ((tid >> 6) & 1u) * 8u;
@@ -118,7 +172,7 @@ __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
 
 template <int COMPS, int STRATEGY>
 __device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = etc1_locate_tile<STRATEGY>(P);
+  const TileCoord t = etc1_locate_tile<STRATEGY, COMPS>(P);
   if (STRATEGY == 3 || !ICAMD_ETC1_REGROUP) {
     if (!t.valid) return;
     uint32_t px[16];

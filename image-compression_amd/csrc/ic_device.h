@@ -241,13 +241,14 @@ struct TileCoord {
 // row-dependent quantity is workgroup-uniform as well.
 // WIDE_ROWS > 1: the workgroup covers WIDE_ROWS block rows and every lane encodes WIDE_ROWS vertically adjacent blocks
 // (the returned coordinate is the first one; the caller steps brow0 / brow).
+// tile_col: the tile column this workgroup takes (blockIdx.x, unless the kernel deals the columns out differently)
 template <bool WIDE, uint32_t WIDE_ROWS = 1>
-__device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
+__device__ __forceinline__ TileCoord locate_tile(const GridParams &P, uint32_t tile_col) {
   TileCoord t;
   const uint32_t cols = WIDE ? 256u : 1u << P.log2_tile_cols, rows = WIDE ? WIDE_ROWS : 256u >> P.log2_tile_cols;
   t.lx = WIDE ? threadIdx.x : threadIdx.x & (cols - 1u);
   t.ly = WIDE ? 0u : threadIdx.x >> P.log2_tile_cols;
-  t.bcol0 = blockIdx.x * cols;
+  t.bcol0 = tile_col * cols;
   t.brow0 = (blockIdx.y + P.tile_row0) * rows;
   t.bcol = t.bcol0 + t.lx;
   t.brow = t.brow0 + t.ly;
@@ -256,6 +257,10 @@ __device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
   t.interior = (t.bcol0 + cols) * 4u <= P.width && (t.brow0 + rows) * 4u <= P.height;
   t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
   return t;
+}
+template <bool WIDE, uint32_t WIDE_ROWS = 1>
+__device__ __forceinline__ TileCoord locate_tile(const GridParams &P) {
+  return locate_tile<WIDE, WIDE_ROWS>(P, blockIdx.x);
 }
 // The block's first source byte = uniform 64-bit base + 32-bit lane offset (<= 4 * 256 rows of stride).
 struct TileSrc {

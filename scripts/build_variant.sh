@@ -6,11 +6,11 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; FLAGS=$2
 O=$R/ab_libs/obj_$NAME; mkdir -p "$O"
-for f in ic_capi dxt_kernels etc1_kernels pvrtc_kernels decode_kernels blockops_kernels diag_kernels; do
+for f in ic_capi dxt_kernels etc1_kernels pvrtc_kernels decode_kernels blockops_kernels diag_kernels rccl_gather; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fvisibility=hidden -I$R/include -I$R/image-compression_amd/csrc $FLAGS \
     -c $R/image-compression_amd/csrc/$f.hip -o $O/$f.o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/libic_amd_$NAME.so $O/*.o -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/libic_amd_$NAME.so $O/*.o -ldl -Wl,-rpath,/opt/rocm/lib
 rm -rf "$O"
 echo "built ab_libs/libic_amd_$NAME.so"
