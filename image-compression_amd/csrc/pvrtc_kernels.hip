@@ -185,6 +185,12 @@ struct PvrtcLaunch {
   // rectangle of 2^log2_rw x 2^(log2_rblocks - log2_rw) blocks at (rx0, ry0).  Whole image: 0, 0, log2_bw, log2_bpi, 0.
   uint32_t rx0, ry0, log2_rw, log2_rblocks, z_first;
   uint32_t stage_stores;    // encode kernel: park the strip's blocks in LDS and write them out in Z-order runs
+  // One-pass kernel with halo columns (r06; textures wider than one workgroup, regions): a workgroup covers 2^log2_wgc block
+  // columns of the 2^log2_rw the rectangle is wide; `halo` holds the reduced colours of the two block columns either side of
+  // every workgroup boundary, [image][boundary 0 .. groups][side 0 = the column left of it, 1 = right][row 0 .. halo_rows),
+  // row i = block row ry0 + i - 1 of the rectangle (its one-block ring included), written by icamd_pvrtc2_halo_morph_kernel.
+  uint2 *halo = nullptr;
+  uint32_t log2_wgc = 0, halo_rows = 0;
 };
 
 // Morph: kMorphBlocksPerLane blocks per lane, software-pipelined with two pixel buffers -- the loads of the next
@@ -309,6 +315,30 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rec
   uint32_t a, c;
   pvrtc_extremes(px, img[0], stash, a, c);
   L.ab[(by << L.log2_bw) + bx] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+}
+
+// Pre-pass of the one-pass kernel's halo form (r06): the reduced colours of the block columns either side of every workgroup
+// boundary -- column rx0 + (b << log2_wgc) - 1 + side for boundary b = 0 .. groups, all halo_rows block rows of the rectangle and
+// its ring.  One lane per (row, column): grid = (row chunks, 2 (groups + 1), images).  A few thousand blocks per texture (0.4 % of
+// an 8192^2 texture's pixels): what lets a block row be SPLIT over several workgroups without morphing whole columns twice.
+extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_halo_morph_kernel(PvrtcLaunch L) {
+  __shared__ uint32_t lds_stash[8][kMorphLanes][4];
+  const uint32_t i = blockIdx.x * kMorphLanes + threadIdx.x;
+  if (i >= L.halo_rows) return;
+  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
+  const uint32_t b = blockIdx.y >> 1, side = blockIdx.y & 1u, image = blockIdx.z;
+  const uint32_t bx = (L.rx0 + (b << L.log2_wgc) - 1u + side) & bw_mask, by = (L.ry0 + i - 1u) & bh_mask;
+  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
+  uint32_t px[32];
+  load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
+#pragma unroll
+  for (int k = 0; k < 32; ++k) px[k] = opaque(px[k]);  // all eight loads in flight before the reduction starts
+  Stash32 stash;
+  stash.base = &lds_stash[0][threadIdx.x][0];
+  stash.row_dwords = kMorphLanes * 4;
+  uint32_t a, c;
+  pvrtc_extremes(px, img[0], stash, a, c);
+  L.halo[((size_t)image * gridDim.y + blockIdx.y) * L.halo_rows + i] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
 }
 
 // LDS tile of the staged stores: a wave's lanes are grouped in chunks of 2^sb consecutive block columns (sb =
@@ -611,13 +641,28 @@ __device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {  // lane i
   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
 }
 
-extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(PvrtcLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+// HALO (r06): the workgroup covers 2^log2_wgc block columns of a WIDER rectangle -- a whole texture of 8192^2 and more, whose block
+// row does not fit 512 lanes, or a region of one texture (icamd_pvrtc2_encode_region_device) -- so the wrap no longer closes inside
+// it.  What the first and the last lane need from outside: the colours of the block column beyond the edge (every segment) and,
+// for the last lane, the column-0 modulation values of the blocks right of its own (the term sum_y |m(7, y) - m(8, y)|,
+// pvrtc.cc:426-429).  The colours of the columns either side of every workgroup boundary come from a tiny pre-pass
+// (icamd_pvrtc2_halo_morph_kernel); a prologue copies this workgroup's share into LDS and computes the 4 K column-0 values from
+// them, one pixel per lane (pvrtc_left_edge_mod, the pair path's routine for the same job) -- and from then on the edge waves read
+// their neighbours' records at the same point, with the same instructions, as every other wave reads the next wave's: the walk, its
+// ring protocol and its instruction count are unchanged.  Output and strip coordinates are LOCAL to the rectangle (an aligned
+// Z-order range is the Z order of its local coordinates), pixels are addressed in the texture.
+template <bool HALO>
+__device__ __forceinline__ void pvrtc2_onepass_body(const PvrtcLaunch &L, uint32_t *lds_dyn) {
   const uint32_t n = L.size, log2_n = L.log2_bw + 3u;
   const uint32_t sb = L.log2_strip, K = 1u << sb;
-  const uint32_t log2_spi = L.log2_bw + 1u - sb;  // strips per image = (size / 4) >> sb
-  const uint32_t image = blockIdx.x >> log2_spi, by0 = (blockIdx.x & ((1u << log2_spi) - 1u)) << sb;
-  const uint32_t bx = threadIdx.x, lane = threadIdx.x & 63u;
+  const uint32_t log2_rh = L.log2_rblocks - L.log2_rw;
+  const uint32_t log2_spi = (HALO ? log2_rh : L.log2_bw + 1u) - sb;  // strips per image (rectangle) = its block rows >> sb
+  const uint32_t log2_g = HALO ? L.log2_rw - L.log2_wgc : 0u;       // workgroups per block row of the rectangle
+  const uint32_t group = HALO ? blockIdx.x & ((1u << log2_g) - 1u) : 0u, strip_id = blockIdx.x >> log2_g;
+  const uint32_t image = strip_id >> log2_spi, by0_local = (strip_id & ((1u << log2_spi) - 1u)) << sb;
+  const uint32_t cx0_local = group << L.log2_wgc;
+  const uint32_t by0 = (HALO ? L.ry0 : 0u) + by0_local;
+  const uint32_t bx_local = cx0_local + threadIdx.x, bx = (HALO ? L.rx0 : 0u) + bx_local, lane = threadIdx.x & 63u;
   const uint32_t W = blockDim.x >> 6;
   const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
@@ -628,6 +673,41 @@ extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(Pv
   const uint32_t ring_lane_byte = (uint32_t)(uintptr_t)ring + lane * 16u;
   const uint32_t tile_byte = (uint32_t)(uintptr_t)ring + kOnePassRing * 2048u;
   const uint32_t xch_byte = (uint32_t)(uintptr_t)(lds_u32 *)(lds_dyn + W * kOnePassWaveDwords);
+  // HALO: after the exchange slots, per segment s = -1 .. K + 1: the colours left of lane 0 (8 bytes), and a 16-byte record
+  // { colours right of the last lane, column-0 values of the block right of block s - 2, - } -- the layout of the exchange slots
+  uint32_t halo_left_byte = 0, halo_right_byte = 0;
+  if (HALO) {
+    uint32_t *tab = lds_dyn + W * (kOnePassWaveDwords + 2u * kOnePassXchDwords);
+    uint2 *tl = reinterpret_cast<uint2 *>(tab);
+    uint4 *tr = reinterpret_cast<uint4 *>(tab + 2u * (K + 4u));  // ((K + 4) * 8 bytes: a multiple of 16)
+    halo_left_byte = (uint32_t)(uintptr_t)(lds_u32 *)tab;
+    halo_right_byte = (uint32_t)(uintptr_t)(lds_u32 *)(tab + 2u * (K + 4u));
+    const uint32_t rows = L.halo_rows, boundaries = (1u << log2_g) + 1u;
+    const uint2 *h_left = L.halo + ((size_t)(image * boundaries + group) * 2u + 0u) * rows;           // column cx0 - 1
+    const uint2 *h_last = L.halo + ((size_t)(image * boundaries + group + 1u) * 2u + 0u) * rows;      // our own last column
+    const uint2 *h_right = L.halo + ((size_t)(image * boundaries + group + 1u) * 2u + 1u) * rows;     // column cx0 + 2^log2_wgc
+    for (uint32_t e = threadIdx.x; e < K + 3u; e += blockDim.x) {
+      // segment s = e - 1 refers to block row by0_local + s of the rectangle = table row by0_local + e (clamped: the last
+      // segment's colours are never used)
+      const uint32_t row = by0_local + e < rows ? by0_local + e : rows - 1u;
+      tl[e] = h_left[row];
+      const uint2 c = h_right[row];
+      tr[e].x = c.x;
+      tr[e].y = c.y;
+    }
+    for (uint32_t t = threadIdx.x; t < 4u * K; t += blockDim.x) {  // (a 64-lane workgroup with 64-block strips: four rounds)
+      // column-0 modulation value of pixel row y_in of the block right of block j (pvrtc.cc:216-227 with xw = 4)
+      const uint32_t j = t >> 2, y_in = t & 3u;
+      const uint32_t right_bx = (bx - threadIdx.x + (1u << L.log2_wgc)) & ((1u << L.log2_bw) - 1u);
+      const uint32_t y = ((by0 + j) * 4u + y_in) & (n - 1u);
+      const uint32_t pixel = img[(y << log2_n) + right_bx * 8u];
+      const uint32_t up = by0_local + j + (y_in < 2u ? 0u : 1u);  // table row of the upper of the two colour rows
+      const uint2 ul = h_last[up], uc = h_right[up], ll = h_last[up + 1u], lc = h_right[up + 1u];
+      const PvrtcColors cul = { ul.x, ul.y }, cuc = { uc.x, uc.y }, cll = { ll.x, ll.y }, clc = { lc.x, lc.y };
+      reinterpret_cast<uint8_t *>(&tr[j + 3u].z)[y_in] = (uint8_t)pvrtc_left_edge_mod(pixel, y_in, cul, cuc, cll, clc);
+    }
+    __syncthreads();
+  }
 
   // pixel row m of the strip (-4 ... 4 K + 3; requests past the end re-fetch the last row so that the wait counts stay
   // uniform) -> ring slot m mod 8, [half][lane][4 pixels]
@@ -677,7 +757,9 @@ extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(Pv
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     uint2 l;
     uint4 r;
-    const uint32_t al = x + left_wave * (kOnePassXchDwords * 4u), ar = x + right_wave * (kOnePassXchDwords * 4u);
+    // (HALO: the first wave's left neighbour and the last wave's right neighbour are the prologue's records of segment s)
+    const uint32_t al = HALO && wave_s == 0u ? halo_left_byte + (uint32_t)(s + 1) * 8u - 16u : x + left_wave * (kOnePassXchDwords * 4u);
+    const uint32_t ar = HALO && wave_s + 1u == W ? halo_right_byte + (uint32_t)(s + 1) * 16u : x + right_wave * (kOnePassXchDwords * 4u);
     asm volatile("ds_read_b64 %0, %2 offset:16\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(r) : "v"(al), "v"(ar) : "memory");
     const uint32_t la = dpp_from_lower_lane(own.a), lb = dpp_from_lower_lane(own.b);
     const uint32_t ra = dpp_from_upper_lane(own.a), rb = dpp_from_upper_lane(own.b), rc = dpp_from_upper_lane(col0);
@@ -687,25 +769,25 @@ extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(Pv
   };
   // this lane's slot of block row jj (0..3) in the wave's tile: chunk = lane / 4, Z order inside (x odd bits, y even bits)
   const uint32_t tile_lane_byte = tile_byte + ((lane >> 2) * kOnePassChunkSlots + (((lane & 1u) | (lane & 2u) << 1) << 1)) * 8u;
-  const uint32_t zx = spread_bits16(bx) << 1;
+  const uint32_t zx = spread_bits16(bx_local) << 1;
   // write-out of four finished block rows: 2 rounds, a lane stores 16 bytes (two Z-adjacent blocks), 8 lanes one 128-byte run
   uint32_t flush_lds[2], flush_zx[2];
 #pragma unroll
   for (uint32_t t = 0; t < 2; ++t) {
     const uint32_t p = t * 64u + lane, chunk = p >> 3, within = (p & 7u) << 1;
     flush_lds[t] = tile_byte + (chunk * kOnePassChunkSlots + within) * 8u;
-    flush_zx[t] = (spread_bits16(wave_s * 64u + 4u * chunk) << 1) + within;
+    flush_zx[t] = (spread_bits16(cx0_local + wave_s * 64u + 4u * chunk) << 1) + within;
   }
   auto store = [&](uint32_t j, uint32_t data, bool one_bpp, const PvrtcColors &own) {
     const uint2 v = make_uint2(data, pvrtc_pack_colors(own.a, own.b, one_bpp));
     if (!L.stage_stores) {
-      asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + (zx | spread_bits16(by0 + j))), "v"(v) : "memory");
+      asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + (zx | spread_bits16(by0_local + j))), "v"(v) : "memory");
       return;
     }
     const uint32_t jj = j & 3u;
     asm volatile("ds_write_b64 %0, %1" :: "v"(tile_lane_byte + ((jj & 1u) | (jj & 2u) << 1) * 8u), "v"(v) : "memory");
     if (jj != 3u) return;
-    const uint32_t zy = spread_bits16(by0 + j - 3u);  // a multiple of 4: its bits do not meet `within`
+    const uint32_t zy = spread_bits16(by0_local + j - 3u);  // a multiple of 4: its bits do not meet `within`
 #pragma unroll
     for (uint32_t t = 0; t < 2; ++t) {
       icamd_u32x4 q;
@@ -723,6 +805,15 @@ extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(Pv
 #endif
 }
 
+extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_kernel(PvrtcLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  pvrtc2_onepass_body<false>(L, lds_dyn);
+}
+extern "C" __global__ void __launch_bounds__(512) icamd_pvrtc2_onepass_halo_kernel(PvrtcLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  pvrtc2_onepass_body<true>(L, lds_dyn);
+}
+
 // the kernel whole-texture launches of 512^2 ... 4096^2 take (launch_pvrtc2); smaller / larger / partial ones: morph + encode
 const char *pvrtc2_kernel_name() { return "icamd_pvrtc2_onepass_kernel"; }
 
@@ -737,51 +828,6 @@ uint32_t compact_even_bits_host(uint32_t v) {
   return v;
 }
 }  // namespace
-
-// One image, blocks [z_first, z_first + n_blocks) of its Z-order output (n_blocks a power of two, z_first a multiple
-// of it: a rectangle of the block grid).  Reads the region's pixels and a one-block ring around it only.
-static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream) {
-  const uint32_t log2_bw = P.log2_size - 3, log2_bpi = 2 * P.log2_size - 5;
-  uint32_t m = 0;
-  while ((1u << m) < P.region_blocks) ++m;
-  if ((1u << m) != P.region_blocks || m > log2_bpi || (P.region_first & (P.region_blocks - 1u)) != 0 ||
-      (uint64_t)P.region_first + P.region_blocks > (1ull << log2_bpi))
-    return hipErrorInvalidValue;
-  uint2 *ab = nullptr;
-  Workspace &ws = g_tls_workspace.get();
-  hipError_t e = ws.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
-  if (e != hipSuccess) return e;
-  (void)hipGetLastError();
-  PvrtcLaunch L;
-  L.src = P.src;
-  L.dst = P.dst;
-  L.ab = ab;
-  L.src_image_stride = L.dst_image_stride = 0;
-  L.size = P.size;
-  L.log2_bw = log2_bw;
-  L.log2_bpi = log2_bpi;
-  L.log2_rblocks = m;
-  L.log2_rw = m / 2;  // x owns the odd bits of the Z index: floor(m/2) of the low m bits
-  const uint32_t log2_rh = m - L.log2_rw;
-  L.rx0 = compact_even_bits_host(P.region_first >> 1);
-  L.ry0 = compact_even_bits_host(P.region_first);
-  L.z_first = P.region_first;
-  L.log2_strip = log2_rh < 3 ? log2_rh : 3;
-  while (L.log2_strip > 0 && (P.region_blocks >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
-  // the staged write-out issues 16-byte stores: only when the region's output is 16-byte aligned (8 is the contract)
-  const bool dst16 = reinterpret_cast<uintptr_t>(P.dst) % 16u == 0;
-  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip && dst16) ? 1u : 0u;
-  L.total_blocks = 1u << log2_bpi;
-  L.total_strips = P.region_blocks >> L.log2_strip;
-  const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
-  const dim3 gm((rw + 2 + kMorphLanes - 1) / kMorphLanes, rh + 2), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
-  hipLaunchKernelGGL(icamd_pvrtc2_morph_rect_kernel, gm, dim3(kMorphLanes), 0, stream, L);
-  hipLaunchKernelGGL(L.log2_rw >= 6 ? icamd_pvrtc2_encode_kernel : icamd_pvrtc2_encode_narrow_kernel, ge, dim3(kEncodeLanes),
-                     0, stream, L);
-  e = hipGetLastError();
-  const hipError_t e2 = ws.release(stream);
-  return e != hipSuccess ? e : e2;
-}
 
 // ---- path selection: one pass (whole textures of 512^2 ... 4096^2, enough of them to fill the chip) or morph + encode --------
 namespace {
@@ -873,7 +919,148 @@ hipError_t launch_pvrtc2_onepass(const PvrtcParams &P, int sb, hipStream_t strea
   hipLaunchKernelGGL(icamd_pvrtc2_onepass_kernel, dim3((uint32_t)(P.n_images * (uint64_t)strips_per_image)), dim3(bw), lds_bytes, stream, L);
   return hipGetLastError();
 }
+
+// Halo form (r06): the rectangle (rx0, ry0, 2^log2_rw x 2^log2_rh blocks; a whole texture: 0, 0, bw, bh) of each image, workgroups
+// of min(2^log2_rw, 512) lanes, strips of 2^sb block rows.  Needs (groups + 1) x 2 columns x (rows + 2) x 8 bytes of scratch per
+// image for the halo colours -- 64 KiB for an 8192^2 texture, against the pair path's 16 MiB.
+struct HaloRect {
+  uint32_t rx0, ry0, log2_rw, log2_rh, z_first;
+};
+constexpr uint32_t kOnePassHaloTableBytes = (64u + 4u) * 8u + (64u + 3u) * 16u;  // strips of at most 64 blocks
+size_t onepass_halo_scratch_bytes(const HaloRect &R, uint64_t n_images) {
+  const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u, groups = 1u << (R.log2_rw - log2_wgc);
+  return (size_t)(n_images * (groups + 1u) * 2u * ((1ull << R.log2_rh) + 2u) * sizeof(uint2));
+}
+hipError_t launch_pvrtc2_onepass_halo(const PvrtcParams &P, const HaloRect &R, int sb, uint2 *scratch, hipStream_t stream) {
+  const uint32_t log2_bw = P.log2_size - 3u;
+  const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u, lanes = 1u << log2_wgc, waves = lanes >> 6;
+  const uint32_t groups = 1u << (R.log2_rw - log2_wgc), rows = (1u << R.log2_rh) + 2u;
+  const size_t lds_bytes = (size_t)waves * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u + kOnePassHaloTableBytes;
+  static std::atomic<uint64_t> allowed{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !((allowed.load() >> dev) & 1u)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(icamd_pvrtc2_onepass_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(8u * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u + kOnePassHaloTableBytes));
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) allowed.fetch_or(1ull << dev);
+  }
+  PvrtcLaunch L;
+  L.src = P.src;
+  L.dst = P.dst;
+  L.ab = nullptr;
+  L.src_image_stride = P.src_image_stride;
+  L.dst_image_stride = P.dst_image_stride;
+  L.size = P.size;
+  L.log2_bw = log2_bw;
+  L.log2_bpi = 2 * P.log2_size - 5;
+  L.log2_strip = (uint32_t)sb;
+  L.rx0 = R.rx0;
+  L.ry0 = R.ry0;
+  L.z_first = R.z_first;
+  L.log2_rw = R.log2_rw;
+  L.log2_rblocks = R.log2_rw + R.log2_rh;
+  L.total_blocks = L.total_strips = 0;
+  L.halo = scratch;
+  L.log2_wgc = log2_wgc;
+  L.halo_rows = rows;
+  L.stage_stores = (reinterpret_cast<uintptr_t>(P.dst) % 16u == 0 && (P.n_images == 1 || P.dst_image_stride % 16u == 0)) ? 1u : 0u;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(icamd_pvrtc2_halo_morph_kernel, dim3((rows + kMorphLanes - 1) / kMorphLanes, 2u * (groups + 1u), P.n_images),
+                     dim3(kMorphLanes), 0, stream, L);
+  const uint64_t wgs = (uint64_t)P.n_images * ((1ull << R.log2_rh) >> sb) * groups;
+  hipLaunchKernelGGL(icamd_pvrtc2_onepass_halo_kernel, dim3((uint32_t)wgs), dim3(lanes), lds_bytes, stream, L);
+  return hipGetLastError();
+}
+// Strip height of the halo form for a rectangle of 2^log2_rw x 2^log2_rh blocks per image, or -1 where the pair is the better
+// choice: the time model of onepass_log2_strip (a K-block strip workgroup: 11 + 5.8 K us whatever its width, 8 / waves of them per
+// CU) + 6 us for the pre-pass launch; the pair: 10 us + 52.6 us per million blocks.
+int onepass_halo_log2_strip(const HaloRect &R, uint64_t n_images, int forced, bool always, uint32_t compute_units) {
+  if (R.log2_rw < 6u || R.log2_rh < 2u) return -1;  // at least one wave wide and one 4-block strip tall
+  if (n_images > 65535u) return -1;                 // (the pre-pass puts the images into grid.z)
+  const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u;
+  const uint64_t groups = 1ull << (R.log2_rw - log2_wgc);
+  const int max_sb = R.log2_rh < 6u ? (int)R.log2_rh : 6;
+  if (forced >= 0) return forced < 2 ? 2 : (forced > max_sb ? max_sb : forced);
+  const uint64_t slots = (uint64_t)compute_units * (8u >> (log2_wgc - 6u));
+  int best = -1;
+  double best_us = 0.0;
+  for (int sb = 2; sb <= max_sb; ++sb) {
+    const uint64_t wgs = (n_images << (R.log2_rh - (uint32_t)sb)) * groups;
+    const double us = 6.0 + (double)((wgs + slots - 1) / slots) * (11.0 + 5.8 * (double)(1u << sb));
+    if (best < 0 || us <= best_us) { best_us = us; best = sb; }
+  }
+  const double pair_us = 10.0 + 52.6e-6 * (double)(n_images << (R.log2_rw + R.log2_rh));
+  return always || best_us < 0.97 * pair_us ? best : -1;
+}
 }  // namespace
+
+// One image, blocks [z_first, z_first + n_blocks) of its Z-order output (n_blocks a power of two, z_first a multiple
+// of it: a rectangle of the block grid).  Reads the region's pixels and a one-block ring around it only.
+static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream) {
+  const uint32_t log2_bw = P.log2_size - 3, log2_bpi = 2 * P.log2_size - 5;
+  uint32_t m = 0;
+  while ((1u << m) < P.region_blocks) ++m;
+  if ((1u << m) != P.region_blocks || m > log2_bpi || (P.region_first & (P.region_blocks - 1u)) != 0 ||
+      (uint64_t)P.region_first + P.region_blocks > (1ull << log2_bpi))
+    return hipErrorInvalidValue;
+  Workspace &ws = g_tls_workspace.get();
+  // r06: regions at least one wave wide and one 4-block strip tall take the one-pass kernel's halo form (one read of the pixels,
+  // (groups + 1) x 2 columns of scratch) -- the multi-GPU split of ONE texture (sharding.pvrtc_region) no longer pays the pair's
+  // second pass over the pixels; icamd_pvrtc2_tune(1, ...) keeps the pair for A/B runs and tests
+  read_path_env();
+  if (g_path_mode.load() != 1) {
+    const uint32_t lrw = m / 2;
+    const HaloRect R = { compact_even_bits_host(P.region_first >> 1), compact_even_bits_host(P.region_first), lrw, m - lrw, P.region_first };
+    const bool force = g_path_mode.load() == 2;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int hsb = onepass_halo_log2_strip(R, 1, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
+    if (hsb >= 0) {
+      uint2 *scratch = nullptr;
+      hipError_t he = ws.acquire(onepass_halo_scratch_bytes(R, 1), stream, reinterpret_cast<void **>(&scratch));
+      if (he != hipSuccess) return he;
+      (void)hipGetLastError();
+      he = launch_pvrtc2_onepass_halo(P, R, hsb, scratch, stream);
+      const hipError_t he2 = ws.release(stream);
+      return he != hipSuccess ? he : he2;
+    }
+  }
+  uint2 *ab = nullptr;
+  hipError_t e = ws.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
+  if (e != hipSuccess) return e;
+  (void)hipGetLastError();
+  PvrtcLaunch L;
+  L.src = P.src;
+  L.dst = P.dst;
+  L.ab = ab;
+  L.src_image_stride = L.dst_image_stride = 0;
+  L.size = P.size;
+  L.log2_bw = log2_bw;
+  L.log2_bpi = log2_bpi;
+  L.log2_rblocks = m;
+  L.log2_rw = m / 2;  // x owns the odd bits of the Z index: floor(m/2) of the low m bits
+  const uint32_t log2_rh = m - L.log2_rw;
+  L.rx0 = compact_even_bits_host(P.region_first >> 1);
+  L.ry0 = compact_even_bits_host(P.region_first);
+  L.z_first = P.region_first;
+  L.log2_strip = log2_rh < 3 ? log2_rh : 3;
+  while (L.log2_strip > 0 && (P.region_blocks >> L.log2_strip) < kFullChipLanes) --L.log2_strip;
+  // the staged write-out issues 16-byte stores: only when the region's output is 16-byte aligned (8 is the contract)
+  const bool dst16 = reinterpret_cast<uintptr_t>(P.dst) % 16u == 0;
+  L.stage_stores = (L.log2_strip >= 1 && L.log2_rw >= L.log2_strip && dst16) ? 1u : 0u;
+  L.total_blocks = 1u << log2_bpi;
+  L.total_strips = P.region_blocks >> L.log2_strip;
+  const uint32_t rw = 1u << L.log2_rw, rh = 1u << log2_rh;
+  const dim3 gm((rw + 2 + kMorphLanes - 1) / kMorphLanes, rh + 2), ge((L.total_strips + kEncodeLanes - 1) / kEncodeLanes);
+  hipLaunchKernelGGL(icamd_pvrtc2_morph_rect_kernel, gm, dim3(kMorphLanes), 0, stream, L);
+  hipLaunchKernelGGL(L.log2_rw >= 6 ? icamd_pvrtc2_encode_kernel : icamd_pvrtc2_encode_narrow_kernel, ge, dim3(kEncodeLanes),
+                     0, stream, L);
+  e = hipGetLastError();
+  const hipError_t e2 = ws.release(stream);
+  return e != hipSuccess ? e : e2;
+}
 
 void pvrtc2_tune(int mode, int log2_strip) {
   read_path_env();
@@ -891,6 +1078,20 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     const int sb = onepass_log2_strip(P.log2_size, P.n_images, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
     if (sb >= 0) return launch_pvrtc2_onepass(P, sb, stream);
+    if (P.log2_size - 3u > 9u) {  // textures of 8192^2 and more (r06): a block row is two or more workgroups wide -> halo form
+      const HaloRect R = { 0u, 0u, P.log2_size - 3u, P.log2_size - 2u, 0u };
+      const int hsb = onepass_halo_log2_strip(R, P.n_images, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
+      if (hsb >= 0) {
+        uint2 *scratch = nullptr;
+        Workspace &hws = g_tls_workspace.get();
+        hipError_t he = hws.acquire(onepass_halo_scratch_bytes(R, P.n_images), stream, reinterpret_cast<void **>(&scratch), P.internal_workspace);
+        if (he != hipSuccess) return he;
+        (void)hipGetLastError();
+        he = launch_pvrtc2_onepass_halo(P, R, hsb, scratch, stream);
+        const hipError_t he2 = hws.release(stream);
+        return he != hipSuccess ? he : he2;
+      }
+    }
   }
   const uint32_t bw = P.size / 8, bh = P.size / 4;
   const uint64_t bpi = (uint64_t)bw * bh;

@@ -204,3 +204,90 @@ def test_single_image_strides_are_checked_like_batches(pkg):
     assert pkg.pad_batch_device(T.DXTC, T.RGB, blocks, 16, 16, 24, 24) is not None
     assert L.icamd_pad_batch_device(T.DXTC, 2, T.RGB, 16, 16, 1, ctypes.c_void_p(blocks.data_ptr()), 0, 24, 24, o, 0, 8 * 6 * 6, None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.fixture
+def pvrtc_auto(pkg):
+    yield
+    pkg.pvrtc_tune(0, -1)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_pvrtc_onepass_halo_form_on_textures_wider_than_a_workgroup(pkg, pvrtc_auto):
+    """r06: textures of 8192^2 and more -- a block row is 1 024 lanes and more -- take the one-pass kernel
+    in its HALO form (icamd_pvrtc2_onepass_halo_kernel: two or more 512-lane workgroups per block row; the colours of the
+    columns either side of every workgroup boundary from a tiny pre-pass, the column-0 values right of a workgroup's last lane
+    from its prologue) instead of the morph + encode pair.  Forced at the shortest and the tallest strip, automatic, and the
+    pair itself, against the oracle; a batch of two with padded strides; an 8-mod-16 destination (no staged stores)."""
+    import hashlib
+    import torch
+    n = 8192
+    img = T.s_smooth(n, n, 4, index=61)
+    img[:2048, :3072] = T.s_noise(2048, 3072, 4, index=61)
+    img[4096:6144, 4000:4200] = T.s_flat(2048, 200, 4, index=61)  # a flat band across the workgroup boundary at x = 4096
+    img[:, 8184:] = T.s_noise(n, 8, 4, index=62)                    # ... and noise either side of the toroidal seam
+    img[:, :8] = T.s_noise(n, 8, 4, index=63)
+    want = T.oracle_encode(T.PVRTC2, img, n, n, 4)
+    d = _dev(img)
+    for mode, sb in ((2, 2), (2, 6), (0, -1), (1, -1)):
+        assert pkg.pvrtc_tune(mode, sb)
+        out = pkg.encode_device(T.PVRTC2, d, n, n, 4)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == want, (mode, sb)
+    # two textures, padded image strides, destination 8 mod 16
+    assert pkg.pvrtc_tune(2, 4)
+    img2 = np.ascontiguousarray(img[::-1, ::-1])
+    want2 = T.oracle_encode(T.PVRTC2, img2, n, n, 4)
+    per_in, per_out = n * n * 4 + 4096, n * n // 4 + 64
+    src = torch.zeros(2 * per_in, dtype=torch.uint8, device="cuda")
+    src[:n * n * 4] = d.view(-1)
+    src[per_in:per_in + n * n * 4] = _dev(img2).view(-1)
+    buf = torch.zeros(2 * per_out + 8, dtype=torch.uint8, device="cuda")
+    import ctypes
+    rc = pkg.lib().icamd_encode_device(pkg.PVRTC2, 0, 4, 0, n, n, n, n, n * 4, 2, per_in, per_out, ctypes.c_void_p(src.data_ptr()),
+                                       ctypes.c_void_p(buf.data_ptr() + 8), None)
+    assert rc == 0, pkg.lib().icamd_last_error()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert got[8:8 + n * n // 4].tobytes() == want and got[8 + per_out:8 + per_out + n * n // 4].tobytes() == want2
+    assert not got[:8].any() and not got[8 + n * n // 4:8 + per_out].any()
+
+
+def test_pvrtc_regions_through_the_halo_form_and_through_the_pair(pkg, pvrtc_auto):
+    """The multi-GPU split of ONE texture (sharding.pvrtc_region -> icamd_pvrtc2_encode_region_device): regions at least 64
+    block columns wide now take the one-pass kernel's halo form.  Every region of 1024^2 ... 4096^2 textures split 2 ... 16 ways,
+    forced through the halo form (shortest / tallest strip), left to the selection, and through the pair -- each from a copy of
+    the texture in which everything outside region + ring + pixel (0, 0) is garbage -- against the oracle."""
+    from image_compression_amd import sharding
+    import torch
+    rng = np.random.Generator(np.random.PCG64(0x6A))
+    for size, worlds in ((1024, (2, 4)), (2048, (2, 8)), (4096, (8, 16))):
+        img = T.soak_image(rng, size, size, 4)
+        want = T.oracle_encode(T.PVRTC2, img, size, size, 4, threads=8)
+        bw, bh = size // 8, size // 4
+        for world in worlds:
+            locals_ = []
+            for rank in range(world):
+                g = sharding.pvrtc_region(size, world, rank)
+                rows, cols = np.zeros(size, bool), np.zeros(size, bool)
+                for j in range(g["blocks_h"] + 2):
+                    by = (g["block_y0"] - 1 + j) % bh
+                    rows[by * 4:by * 4 + 4] = True
+                for i in range(g["blocks_w"] + 2):
+                    bx = (g["block_x0"] - 1 + i) % bw
+                    cols[bx * 8:bx * 8 + 8] = True
+                keep = np.outer(rows, cols)
+                keep[0, 0] = True
+                locals_.append((g, _dev(np.where(keep[..., None], img, rng.integers(0, 256, img.shape, dtype=np.uint8)))))
+            for mode, sb in ((2, 2), (2, 6), (0, -1), (1, -1)):
+                assert pkg.pvrtc_tune(mode, sb)
+                got = bytearray(len(want))
+                for g, local in locals_:
+                    out = pkg.pvrtc_encode_region_device(local, size, g["first_block"], g["n_blocks"])
+                    torch.cuda.synchronize()
+                    got[g["dst_offset_bytes"]:g["dst_offset_bytes"] + g["dst_bytes"]] = out.cpu().numpy().tobytes()
+                assert bytes(got) == want, (size, world, mode, sb)

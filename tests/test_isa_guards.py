@@ -127,6 +127,42 @@ def test_pvrtc_onepass_kernel_ring_protocol_as_compiled(tmp_path):
     assert tail == ["s_waitcnt vmcnt(0)"], tail
 
 
+def test_pvrtc_onepass_halo_kernel_keeps_the_ring_protocol(tmp_path):
+    """r06: icamd_pvrtc2_onepass_halo_kernel is the same walk with a prologue in front (the workgroup's share of the halo table
+    into LDS, the 4 K column-0 values right of its last lane) and two scalar address selects in the exchange.  The prologue is
+    plain code -- its loads and LDS writes sit in front of the first DMA and end in a barrier, so they may be visible to hipcc --
+    but from the first row request on the hand-counted protocol must be exactly the plain kernel's: the loop holds 4 ticks' worth
+    of DMA and `vmcnt(4)` waits, one barrier, no other vmcnt wait, no memory / LDS instruction outside the inline asm."""
+    text = _asm("pvrtc_kernels.hip", tmp_path)
+    meta = _kernel_meta(text, "icamd_pvrtc2_onepass_halo_kernel")
+    assert meta["scratch"] == 0 and 171 <= meta["vgprs"] <= 256 and meta["lds"] == 0, meta
+    body = _body(text, "icamd_pvrtc2_onepass_halo_kernel")
+    first_dma = next(i for i, l in enumerate(body) if "global_load_lds_dwordx4" in l)
+    loop = max(i for i, l in enumerate(body) if "Inner Loop Header" in l)   # (the prologue's copy loop comes first)
+    assert loop > first_dma
+    back = max(i for i, l in enumerate(body) if re.match(r"\s+s_cbranch_\w+\s+\.LBB\d+_\d+", l))
+    assert any(re.match(r"\s+s_barrier", l) for l in body[:first_dma]), "the prologue must end in a barrier before the first row request"
+    in_asm, stray = False, []
+    for i, l in enumerate(body):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif i > first_dma and re.match(r"\s+(ds_|global_|buffer_|flat_|scratch_)", l) and not in_asm and "global_load_lds" not in l:
+            stray.append(l.strip())
+    assert not stray, "memory / LDS instructions outside the inline asm of the walk: %s" % stray[:4]
+    pre = [l for l in body[first_dma:loop] if "global_load_lds_dwordx4" in l]
+    assert len(pre) == 6 + 3 * 2, len(pre)
+    walk = body[loop:back + 1]
+    waits = [re.sub(r"\s+", " ", l.strip()) for l in walk if "s_waitcnt" in l and "vmcnt" in l]
+    assert sum("global_load_lds_dwordx4" in l for l in walk) == 8 and waits == ["s_waitcnt vmcnt(4)"] * 4, waits
+    assert sum(bool(re.match(r"\s+s_barrier", l)) for l in walk) == 1
+    tail = [re.sub(r"\s+", " ", l.strip()) for l in body[back + 1:] if "s_waitcnt" in l and "vmcnt" in l]
+    assert tail == ["s_waitcnt vmcnt(0)"], tail
+    # the pre-pass: light (it morphs a few thousand blocks per texture), no scratch
+    assert _kernel_meta(text, "icamd_pvrtc2_halo_morph_kernel")["scratch"] == 0
+
+
 def test_pvrtc_onepass_kernel_plain_scan_build_still_compiles(tmp_path):
     """-DICAMD_PVRTC_NO_SCAN_SDWA (the early-exit scan as plain C++ instead of the VCC / SDWA sequence) stays buildable."""
     text = _asm("pvrtc_kernels.hip", tmp_path, ["-DICAMD_PVRTC_NO_SCAN_SDWA"])
