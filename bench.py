@@ -75,6 +75,10 @@ CONFIGS = {
                     "GPUs (texture_range per rank, RCCL gather)"),
     "c5": dict(workload="pvrtc2_rgba8", size=4096, batch=16,
                text="PVRTC 2bpp encode 4096x4096 on 1x MI355X (the reference has no 4bpp mode, SURVEY D3)"),
+    # not a BASELINE configuration: config 5's codec on textures whose block row no longer fits one workgroup (r06: the one-pass
+    # kernel's halo form; until r05 the morph + encode pair at 0.31 with 2.2 x the traffic) -- parity pinned like c5
+    "c5_8192": dict(workload="pvrtc2_rgba8", size=8192, batch=4,
+                    text="PVRTC 2bpp encode 8192x8192 (4 textures per launch): a block row is two workgroups wide"),
     # not a BASELINE-pinned leg: config 5's literal "PVRTC 4bpp" as an EXTENSION (no reference implementation to pin it to)
     "c5_4bpp": dict(workload="pvrtc4_rgba8", size=4096, batch=16,
                     text="PVRTC 4bpp encode 4096x4096 on 1x MI355X -- EXTENSION, parity unpinned: the 2bpp rules of the "
@@ -1526,7 +1530,7 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_extra_configs:
             configs = {}
-            for name in ("c3", "c4", "c5", "c5_4bpp"):
+            for name in ("c3", "c4", "c5", "c5_8192", "c5_4bpp"):
                 ctx.leg = "configs." + name
                 try:
                     configs[name] = preset_leg(ctx, pkg, sharding, name, args.extra_steps, verify=not args.no_verify,

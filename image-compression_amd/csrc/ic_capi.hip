@@ -332,7 +332,7 @@ int pvrtc_encode_device_impl(int src_components, uint32_t height, uint32_t width
 extern "C" {
 #pragma GCC visibility push(default)
 
-const char *icamd_version(void) { return "image-compression_amd 0.5 (gfx950)"; }
+const char *icamd_version(void) { return "image-compression_amd 0.6 (gfx950)"; }
 const char *icamd_last_error(void) { return g_last_error; }
 
 int icamd_device_count(void) try {

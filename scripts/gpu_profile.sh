@@ -39,7 +39,7 @@ esac
 # HBM traffic of the BASELINE presets whose launch shape differs from the workload defaults (c3: 4 x 8192^2 DXT5, c4: 1024 x
 # 1024^2 ETC1 kSmallerError): FETCH_SIZE / WRITE_SIZE in separate passes -> profiles/traffic.json "presets"
 if [ -z "${SKIP_PRESETS:-}" ]; then
-  for cfg in c3 c4; do
+  for cfg in c3 c4 c5_8192; do
     B="python bench.py --steps 10 --warmup 2 --precondition-seconds 0 --config $cfg $COMMON"
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/preset_$cfg/pmc_fetch" -o "preset_$cfg" -- $B > "$O/preset_$cfg.fetch.log" 2>&1
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/preset_$cfg/pmc_write" -o "preset_$cfg" -- $B > "$O/preset_$cfg.write.log" 2>&1

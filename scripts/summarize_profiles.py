@@ -126,7 +126,7 @@ def main():
     # shape (16 x 4096^2); c3 / c4 come from their own passes (gpurun_out/prof/preset_cN)
     presets = traffic.setdefault("presets", {})
     shapes = {"c2": ("dxt1_rgba8", 4096, 16), "c3": ("dxt5_rgba8", 8192, 4), "c4": ("etc1_rgb888", 1024, 1024),
-              "c5": ("pvrtc2_rgba8", 4096, 16)}
+              "c5": ("pvrtc2_rgba8", 4096, 16), "c5_8192": ("pvrtc2_rgba8", 8192, 4)}  # (c5_8192, r06: the one-pass kernel's halo form)
     for cfg, (wl, size, n) in shapes.items():
         if cfg in ("c2", "c5"):
             if wl in per_step:

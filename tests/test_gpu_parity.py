@@ -1085,7 +1085,7 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
     d = _run_bench(["--steps", "3", "--warmup", "1", "--extra-steps", "2", "--no-sustained", "--no-single-image", "--no-host-api",
                     "--no-cpu-baseline", "--precondition-seconds", "0"], timeout=900)
     assert d["config"]["preset"] == "c2" and d["parity"].startswith("bit-exact")
-    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp"]
+    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp", "c5_8192"]
     for name, leg in d["configs"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, (name, leg)
     assert d["configs"]["c4"]["textures_per_gpu_per_step"] == 1024 and d["configs"]["c4"]["etc_strategy"] == 2
@@ -1093,7 +1093,8 @@ def test_bench_default_line_carries_every_baseline_config_and_the_slab_legs(pkg)
     # r05: `traffic` is measured in the run itself (two rocprofv3 --pmc child passes per launch shape) and agrees with the
     # committed profile of the same launch shape; algorithmic bytes <= traffic < 1.1 x algorithmic for the one-pass kernels
     for name, roof, algo in [("c2", d["roofline"], 16 * 4096 * 4096 * 4.5), ("c5", d["configs"]["c5"]["roofline"], 16 * 4096 * 4096 * 4.25),
-                             ("c5_4bpp", d["configs"]["c5_4bpp"]["roofline"], 16 * 4096 * 4096 * 4.5)]:
+                             ("c5_4bpp", d["configs"]["c5_4bpp"]["roofline"], 16 * 4096 * 4096 * 4.5),
+                             ("c5_8192", d["configs"]["c5_8192"]["roofline"], 4 * 8192 * 8192 * 4.25)]:  # r06: the halo form
         assert roof["traffic_source"].startswith("measured in this run"), (name, roof["traffic_source"])
         assert algo <= roof["traffic"] < 1.1 * algo, (name, roof["traffic"], algo)
         if roof["traffic_committed_profile"]:
@@ -1139,7 +1140,7 @@ def test_bench_rehearsal_of_the_drivers_eight_rank_command(pkg):
     lp = d["link_probe"]
     assert lp["peers"] == 7 and len(lp["per_peer_alone_GBps"]) == 7 and lp["payload_intact"] and lp["xgmi_links_into_rank0"] == 7
     assert "value_with_gather_ceiling" in d["scaling_headline"]
-    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp"]
+    assert sorted(d["configs"]) == ["c3", "c4", "c5", "c5_4bpp", "c5_8192"]
     for name, leg in d["configs"].items():
         assert leg["parity"].startswith("bit-exact") and leg["value"] > 0 and leg["value_with_gather"] > 0, (name, leg)
         assert leg["rank0_copy_matches"] is True and leg["gather_ranks"] == 8 and leg["gather_bound_GBps"] > 0, (name, leg)
