@@ -185,12 +185,9 @@ struct PvrtcLaunch {
   // rectangle of 2^log2_rw x 2^(log2_rblocks - log2_rw) blocks at (rx0, ry0).  Whole image: 0, 0, log2_bw, log2_bpi, 0.
   uint32_t rx0, ry0, log2_rw, log2_rblocks, z_first;
   uint32_t stage_stores;    // encode kernel: park the strip's blocks in LDS and write them out in Z-order runs
-  // One-pass kernel with halo columns (r06; textures wider than one workgroup, regions): a workgroup covers 2^log2_wgc block
-  // columns of the 2^log2_rw the rectangle is wide; `halo` holds the reduced colours of the two block columns either side of
-  // every workgroup boundary, [image][boundary 0 .. groups][side 0 = the column left of it, 1 = right][row 0 .. halo_rows),
-  // row i = block row ry0 + i - 1 of the rectangle (its one-block ring included), written by icamd_pvrtc2_halo_morph_kernel.
-  uint2 *halo = nullptr;
-  uint32_t log2_wgc = 0, halo_rows = 0;
+  // One-pass kernel, halo form (r06; textures wider than one workgroup, regions): a workgroup covers 2^log2_wgc block columns
+  // of the 2^log2_rw the rectangle is wide
+  uint32_t log2_wgc = 0;
 };
 
 // Morph: kMorphBlocksPerLane blocks per lane, software-pipelined with two pixel buffers -- the loads of the next
@@ -315,30 +312,6 @@ extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_morph_rec
   uint32_t a, c;
   pvrtc_extremes(px, img[0], stash, a, c);
   L.ab[(by << L.log2_bw) + bx] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
-}
-
-// Pre-pass of the one-pass kernel's halo form (r06): the reduced colours of the block columns either side of every workgroup
-// boundary -- column rx0 + (b << log2_wgc) - 1 + side for boundary b = 0 .. groups, all halo_rows block rows of the rectangle and
-// its ring.  One lane per (row, column): grid = (row chunks, 2 (groups + 1), images).  A few thousand blocks per texture (0.4 % of
-// an 8192^2 texture's pixels): what lets a block row be SPLIT over several workgroups without morphing whole columns twice.
-extern "C" __global__ void __launch_bounds__(kMorphLanes) icamd_pvrtc2_halo_morph_kernel(PvrtcLaunch L) {
-  __shared__ uint32_t lds_stash[8][kMorphLanes][4];
-  const uint32_t i = blockIdx.x * kMorphLanes + threadIdx.x;
-  if (i >= L.halo_rows) return;
-  const uint32_t n = L.size, bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
-  const uint32_t b = blockIdx.y >> 1, side = blockIdx.y & 1u, image = blockIdx.z;
-  const uint32_t bx = (L.rx0 + (b << L.log2_wgc) - 1u + side) & bw_mask, by = (L.ry0 + i - 1u) & bh_mask;
-  const uint32_t *img = reinterpret_cast<const uint32_t *>(L.src + (size_t)image * L.src_image_stride);
-  uint32_t px[32];
-  load_block32(img + (size_t)(by * 4u) * n + bx * 8u, n, px);
-#pragma unroll
-  for (int k = 0; k < 32; ++k) px[k] = opaque(px[k]);  // all eight loads in flight before the reduction starts
-  Stash32 stash;
-  stash.base = &lds_stash[0][threadIdx.x][0];
-  stash.row_dwords = kMorphLanes * 4;
-  uint32_t a, c;
-  pvrtc_extremes(px, img[0], stash, a, c);
-  L.halo[((size_t)image * gridDim.y + blockIdx.y) * L.halo_rows + i] = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
 }
 
 // LDS tile of the staged stores: a wave's lanes are grouped in chunks of 2^sb consecutive block columns (sb =
@@ -645,9 +618,10 @@ __device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {  // lane i
 // row does not fit 512 lanes, or a region of one texture (icamd_pvrtc2_encode_region_device) -- so the wrap no longer closes inside
 // it.  What the first and the last lane need from outside: the colours of the block column beyond the edge (every segment) and,
 // for the last lane, the column-0 modulation values of the blocks right of its own (the term sum_y |m(7, y) - m(8, y)|,
-// pvrtc.cc:426-429).  The colours of the columns either side of every workgroup boundary come from a tiny pre-pass
-// (icamd_pvrtc2_halo_morph_kernel); a prologue copies this workgroup's share into LDS and computes the 4 K column-0 values from
-// them, one pixel per lane (pvrtc_left_edge_mod, the pair path's routine for the same job) -- and from then on the edge waves read
+// pvrtc.cc:426-429).  A PROLOGUE reduces those two columns (and the workgroup's own last one) itself -- 3 (K + 3) blocks, one per
+// lane, with the pair path's routine and the idle row ring as its stash -- and computes the 4 K column-0 values from them, one
+// pixel per lane (pvrtc_left_edge_mod, the pair path's routine for the same job): no pre-pass, no scratch memory, so these
+// launches too can be captured without a workspace -- and from then on the edge waves read
 // their neighbours' records at the same point, with the same instructions, as every other wave reads the next wave's: the walk, its
 // ring protocol and its instruction count are unchanged.  Output and strip coordinates are LOCAL to the rectangle (an aligned
 // Z-order range is the Z order of its local coordinates), pixels are addressed in the texture.
@@ -673,37 +647,50 @@ __device__ __forceinline__ void pvrtc2_onepass_body(const PvrtcLaunch &L, uint32
   const uint32_t ring_lane_byte = (uint32_t)(uintptr_t)ring + lane * 16u;
   const uint32_t tile_byte = (uint32_t)(uintptr_t)ring + kOnePassRing * 2048u;
   const uint32_t xch_byte = (uint32_t)(uintptr_t)(lds_u32 *)(lds_dyn + W * kOnePassWaveDwords);
-  // HALO: after the exchange slots, per segment s = -1 .. K + 1: the colours left of lane 0 (8 bytes), and a 16-byte record
-  // { colours right of the last lane, column-0 values of the block right of block s - 2, - } -- the layout of the exchange slots
+  // HALO: after the exchange slots, per segment s = -1 .. K + 1: the colours left of lane 0 (8 bytes), a 16-byte record
+  // { colours right of the last lane, column-0 values of the block right of block s - 2, - } -- the layout of the exchange
+  // slots -- and the colours of the workgroup's own last column (the prologue's edge values need them before the walk has them)
   uint32_t halo_left_byte = 0, halo_right_byte = 0;
   if (HALO) {
     uint32_t *tab = lds_dyn + W * (kOnePassWaveDwords + 2u * kOnePassXchDwords);
     uint2 *tl = reinterpret_cast<uint2 *>(tab);
     uint4 *tr = reinterpret_cast<uint4 *>(tab + 2u * (K + 4u));  // ((K + 4) * 8 bytes: a multiple of 16)
+    uint2 *tlast = reinterpret_cast<uint2 *>(tab + 2u * (K + 4u) + 4u * (K + 3u));
     halo_left_byte = (uint32_t)(uintptr_t)(lds_u32 *)tab;
     halo_right_byte = (uint32_t)(uintptr_t)(lds_u32 *)(tab + 2u * (K + 4u));
-    const uint32_t rows = L.halo_rows, boundaries = (1u << log2_g) + 1u;
-    const uint2 *h_left = L.halo + ((size_t)(image * boundaries + group) * 2u + 0u) * rows;           // column cx0 - 1
-    const uint2 *h_last = L.halo + ((size_t)(image * boundaries + group + 1u) * 2u + 0u) * rows;      // our own last column
-    const uint2 *h_right = L.halo + ((size_t)(image * boundaries + group + 1u) * 2u + 1u) * rows;     // column cx0 + 2^log2_wgc
-    for (uint32_t e = threadIdx.x; e < K + 3u; e += blockDim.x) {
-      // segment s = e - 1 refers to block row by0_local + s of the rectangle = table row by0_local + e (clamped: the last
-      // segment's colours are never used)
-      const uint32_t row = by0_local + e < rows ? by0_local + e : rows - 1u;
-      tl[e] = h_left[row];
-      const uint2 c = h_right[row];
-      tr[e].x = c.x;
-      tr[e].y = c.y;
+    const uint32_t bw_mask = (1u << L.log2_bw) - 1u, bh_mask = (2u << L.log2_bw) - 1u;
+    const uint32_t first_bx = bx - threadIdx.x, wgc = 1u << L.log2_wgc;
+    // (1) GetExtremesFast + channel reduction of the three block columns the workgroup does not walk itself or needs early --
+    // left of it, its own last one, right of it -- for the strip's K + 3 colour rows: 3 (K + 3) blocks, one per lane and round
+    // (the pair path's routine; its per-lane pixel stash aliases the row ring, which is idle until the walk starts).  The same
+    // columns are reduced again by the neighbouring workgroup: 3 / 512 of the morph.
+    Stash32 stash;
+    stash.base = lds_dyn + threadIdx.x * 4u;
+    stash.row_dwords = blockDim.x * 4u;
+    for (uint32_t t = threadIdx.x; t < 3u * (K + 3u); t += blockDim.x) {
+      const uint32_t col = t < K + 3u ? 0u : (t < 2u * (K + 3u) ? 1u : 2u), e = t - col * (K + 3u);
+      const uint32_t hx = (col == 0u ? first_bx - 1u : (col == 1u ? first_bx + wgc - 1u : first_bx + wgc)) & bw_mask;
+      const uint32_t hy = (by0 + e - 1u) & bh_mask;  // segment s = e - 1 refers to block row by0 + s
+      uint32_t px[32];
+      load_block32(img + (size_t)(hy * 4u) * n + hx * 8u, n, px);
+      uint32_t a, c;
+      pvrtc_extremes(px, image0, stash, a, c);
+      const uint2 v = make_uint2(channel_reduce(a, false), channel_reduce(c, true));
+      if (col == 0u) tl[e] = v;
+      else if (col == 1u) tlast[e] = v;
+      else { tr[e].x = v.x; tr[e].y = v.y; }
     }
+    __syncthreads();
+    // (2) the column-0 modulation values of the blocks right of the last lane's, one pixel per lane and round
     for (uint32_t t = threadIdx.x; t < 4u * K; t += blockDim.x) {  // (a 64-lane workgroup with 64-block strips: four rounds)
-      // column-0 modulation value of pixel row y_in of the block right of block j (pvrtc.cc:216-227 with xw = 4)
+      // pixel row y_in of the block right of block j (pvrtc.cc:216-227 with xw = 4)
       const uint32_t j = t >> 2, y_in = t & 3u;
-      const uint32_t right_bx = (bx - threadIdx.x + (1u << L.log2_wgc)) & ((1u << L.log2_bw) - 1u);
+      const uint32_t right_bx = (first_bx + wgc) & bw_mask;
       const uint32_t y = ((by0 + j) * 4u + y_in) & (n - 1u);
       const uint32_t pixel = img[(y << log2_n) + right_bx * 8u];
-      const uint32_t up = by0_local + j + (y_in < 2u ? 0u : 1u);  // table row of the upper of the two colour rows
-      const uint2 ul = h_last[up], uc = h_right[up], ll = h_last[up + 1u], lc = h_right[up + 1u];
-      const PvrtcColors cul = { ul.x, ul.y }, cuc = { uc.x, uc.y }, cll = { ll.x, ll.y }, clc = { lc.x, lc.y };
+      const uint32_t up = j + (y_in < 2u ? 0u : 1u);  // entry of the upper of the two colour rows (entry e = block row e - 1)
+      const uint2 ul = tlast[up], ll = tlast[up + 1u];
+      const PvrtcColors cul = { ul.x, ul.y }, cuc = { tr[up].x, tr[up].y }, cll = { ll.x, ll.y }, clc = { tr[up + 1u].x, tr[up + 1u].y };
       reinterpret_cast<uint8_t *>(&tr[j + 3u].z)[y_in] = (uint8_t)pvrtc_left_edge_mod(pixel, y_in, cul, cuc, cll, clc);
     }
     __syncthreads();
@@ -921,20 +908,15 @@ hipError_t launch_pvrtc2_onepass(const PvrtcParams &P, int sb, hipStream_t strea
 }
 
 // Halo form (r06): the rectangle (rx0, ry0, 2^log2_rw x 2^log2_rh blocks; a whole texture: 0, 0, bw, bh) of each image, workgroups
-// of min(2^log2_rw, 512) lanes, strips of 2^sb block rows.  Needs (groups + 1) x 2 columns x (rows + 2) x 8 bytes of scratch per
-// image for the halo colours -- 64 KiB for an 8192^2 texture, against the pair path's 16 MiB.
+// of min(2^log2_rw, 512) lanes, strips of 2^sb block rows.  One launch, no scratch memory.
 struct HaloRect {
   uint32_t rx0, ry0, log2_rw, log2_rh, z_first;
 };
-constexpr uint32_t kOnePassHaloTableBytes = (64u + 4u) * 8u + (64u + 3u) * 16u;  // strips of at most 64 blocks
-size_t onepass_halo_scratch_bytes(const HaloRect &R, uint64_t n_images) {
-  const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u, groups = 1u << (R.log2_rw - log2_wgc);
-  return (size_t)(n_images * (groups + 1u) * 2u * ((1ull << R.log2_rh) + 2u) * sizeof(uint2));
-}
-hipError_t launch_pvrtc2_onepass_halo(const PvrtcParams &P, const HaloRect &R, int sb, uint2 *scratch, hipStream_t stream) {
+constexpr uint32_t kOnePassHaloTableBytes = (64u + 4u) * 8u + (64u + 3u) * 16u + (64u + 3u) * 8u;  // strips of at most 64 blocks
+hipError_t launch_pvrtc2_onepass_halo(const PvrtcParams &P, const HaloRect &R, int sb, hipStream_t stream) {
   const uint32_t log2_bw = P.log2_size - 3u;
   const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u, lanes = 1u << log2_wgc, waves = lanes >> 6;
-  const uint32_t groups = 1u << (R.log2_rw - log2_wgc), rows = (1u << R.log2_rh) + 2u;
+  const uint32_t groups = 1u << (R.log2_rw - log2_wgc);
   const size_t lds_bytes = (size_t)waves * (kOnePassWaveDwords + 2u * kOnePassXchDwords) * 4u + kOnePassHaloTableBytes;
   static std::atomic<uint64_t> allowed{0};
   int dev = 0;
@@ -962,23 +944,18 @@ hipError_t launch_pvrtc2_onepass_halo(const PvrtcParams &P, const HaloRect &R, i
   L.log2_rw = R.log2_rw;
   L.log2_rblocks = R.log2_rw + R.log2_rh;
   L.total_blocks = L.total_strips = 0;
-  L.halo = scratch;
   L.log2_wgc = log2_wgc;
-  L.halo_rows = rows;
   L.stage_stores = (reinterpret_cast<uintptr_t>(P.dst) % 16u == 0 && (P.n_images == 1 || P.dst_image_stride % 16u == 0)) ? 1u : 0u;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(icamd_pvrtc2_halo_morph_kernel, dim3((rows + kMorphLanes - 1) / kMorphLanes, 2u * (groups + 1u), P.n_images),
-                     dim3(kMorphLanes), 0, stream, L);
   const uint64_t wgs = (uint64_t)P.n_images * ((1ull << R.log2_rh) >> sb) * groups;
   hipLaunchKernelGGL(icamd_pvrtc2_onepass_halo_kernel, dim3((uint32_t)wgs), dim3(lanes), lds_bytes, stream, L);
   return hipGetLastError();
 }
 // Strip height of the halo form for a rectangle of 2^log2_rw x 2^log2_rh blocks per image, or -1 where the pair is the better
 // choice: the time model of onepass_log2_strip (a K-block strip workgroup: 11 + 5.8 K us whatever its width, 8 / waves of them per
-// CU) + 6 us for the pre-pass launch; the pair: 10 us + 52.6 us per million blocks.
+// CU) + 2 us for the prologue; the pair: 10 us + 52.6 us per million blocks.
 int onepass_halo_log2_strip(const HaloRect &R, uint64_t n_images, int forced, bool always, uint32_t compute_units) {
   if (R.log2_rw < 6u || R.log2_rh < 2u) return -1;  // at least one wave wide and one 4-block strip tall
-  if (n_images > 65535u) return -1;                 // (the pre-pass puts the images into grid.z)
   const uint32_t log2_wgc = R.log2_rw < 9u ? R.log2_rw : 9u;
   const uint64_t groups = 1ull << (R.log2_rw - log2_wgc);
   const int max_sb = R.log2_rh < 6u ? (int)R.log2_rh : 6;
@@ -988,7 +965,7 @@ int onepass_halo_log2_strip(const HaloRect &R, uint64_t n_images, int forced, bo
   double best_us = 0.0;
   for (int sb = 2; sb <= max_sb; ++sb) {
     const uint64_t wgs = (n_images << (R.log2_rh - (uint32_t)sb)) * groups;
-    const double us = 6.0 + (double)((wgs + slots - 1) / slots) * (11.0 + 5.8 * (double)(1u << sb));
+    const double us = 2.0 + (double)((wgs + slots - 1) / slots) * (11.0 + 5.8 * (double)(1u << sb));
     if (best < 0 || us <= best_us) { best_us = us; best = sb; }
   }
   const double pair_us = 10.0 + 52.6e-6 * (double)(n_images << (R.log2_rw + R.log2_rh));
@@ -1005,10 +982,9 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
   if ((1u << m) != P.region_blocks || m > log2_bpi || (P.region_first & (P.region_blocks - 1u)) != 0 ||
       (uint64_t)P.region_first + P.region_blocks > (1ull << log2_bpi))
     return hipErrorInvalidValue;
-  Workspace &ws = g_tls_workspace.get();
-  // r06: regions at least one wave wide and one 4-block strip tall take the one-pass kernel's halo form (one read of the pixels,
-  // (groups + 1) x 2 columns of scratch) -- the multi-GPU split of ONE texture (sharding.pvrtc_region) no longer pays the pair's
-  // second pass over the pixels; icamd_pvrtc2_tune(1, ...) keeps the pair for A/B runs and tests
+  // r06: regions at least one wave wide and one 4-block strip tall take the one-pass kernel's halo form where the time model
+  // prefers it (one read of the pixels, one launch, no scratch) -- the multi-GPU split of ONE large texture (sharding.pvrtc_region)
+  // no longer pays the pair's second pass over the pixels; icamd_pvrtc2_tune(1, ...) keeps the pair for A/B runs and tests
   read_path_env();
   if (g_path_mode.load() != 1) {
     const uint32_t lrw = m / 2;
@@ -1017,17 +993,10 @@ static hipError_t launch_pvrtc2_region(const PvrtcParams &P, hipStream_t stream)
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int hsb = onepass_halo_log2_strip(R, 1, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
-    if (hsb >= 0) {
-      uint2 *scratch = nullptr;
-      hipError_t he = ws.acquire(onepass_halo_scratch_bytes(R, 1), stream, reinterpret_cast<void **>(&scratch));
-      if (he != hipSuccess) return he;
-      (void)hipGetLastError();
-      he = launch_pvrtc2_onepass_halo(P, R, hsb, scratch, stream);
-      const hipError_t he2 = ws.release(stream);
-      return he != hipSuccess ? he : he2;
-    }
+    if (hsb >= 0) return launch_pvrtc2_onepass_halo(P, R, hsb, stream);
   }
   uint2 *ab = nullptr;
+  Workspace &ws = g_tls_workspace.get();
   hipError_t e = ws.acquire(((size_t)sizeof(uint2)) << log2_bpi, stream, reinterpret_cast<void **>(&ab));
   if (e != hipSuccess) return e;
   (void)hipGetLastError();
@@ -1081,16 +1050,7 @@ hipError_t launch_pvrtc2(const PvrtcParams &P, hipStream_t stream) {
     if (P.log2_size - 3u > 9u) {  // textures of 8192^2 and more (r06): a block row is two or more workgroups wide -> halo form
       const HaloRect R = { 0u, 0u, P.log2_size - 3u, P.log2_size - 2u, 0u };
       const int hsb = onepass_halo_log2_strip(R, P.n_images, force ? g_path_strip.load() : -1, force, device_compute_units(dev));
-      if (hsb >= 0) {
-        uint2 *scratch = nullptr;
-        Workspace &hws = g_tls_workspace.get();
-        hipError_t he = hws.acquire(onepass_halo_scratch_bytes(R, P.n_images), stream, reinterpret_cast<void **>(&scratch), P.internal_workspace);
-        if (he != hipSuccess) return he;
-        (void)hipGetLastError();
-        he = launch_pvrtc2_onepass_halo(P, R, hsb, scratch, stream);
-        const hipError_t he2 = hws.release(stream);
-        return he != hipSuccess ? he : he2;
-      }
+      if (hsb >= 0) return launch_pvrtc2_onepass_halo(P, R, hsb, stream);
     }
   }
   const uint32_t bw = P.size / 8, bh = P.size / 4;

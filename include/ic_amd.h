@@ -117,8 +117,8 @@ int icamd_pvrtc2_set_workspace(void *d_workspace, size_t bytes);
  * pvrtc_compressor.cc:586-597 in ONE read of the pixels, no scratch memory -- such launches can be captured into a HIP graph
  * without a caller-owned workspace).  Textures of 8192^2 and more, and regions (icamd_pvrtc2_encode_region_device) at least 64
  * block columns wide, take the same kernel in its HALO form where the time model prefers it (r06: a block row split over several
- * workgroups; a few KiB of scratch per texture for the colours of the boundary columns -- under stream capture from the caller's
- * workspace, like the pair's).  Everything else takes the morph + encode pair.  mode 0 = automatic (default; also the
+ * workgroups, each reducing the block columns beyond its edges itself -- still one launch and no scratch memory).  Everything
+ * else takes the morph + encode pair.  mode 0 = automatic (default; also the
  * value of the environment variable ICAMD_PVRTC2_PATH=auto|two|one read at the first launch), 1 = always the pair, 2 = one pass
  * wherever eligible; log2_strip < 0 = automatic strip height (blocks per lane) of the one-pass kernel (2 ... 6), else that height, clamped to
  * 2 ... log2(size / 4) (the tallest strip is the whole texture: one workgroup per texture).

@@ -130,7 +130,8 @@ def test_pvrtc_onepass_kernel_ring_protocol_as_compiled(tmp_path):
 def test_pvrtc_onepass_halo_kernel_keeps_the_ring_protocol(tmp_path):
     """r06: icamd_pvrtc2_onepass_halo_kernel is the same walk with a prologue in front (the workgroup's share of the halo table
     into LDS, the 4 K column-0 values right of its last lane) and two scalar address selects in the exchange.  The prologue is
-    plain code -- its loads and LDS writes sit in front of the first DMA and end in a barrier, so they may be visible to hipcc --
+    plain code (the reduction of the three halo columns with the pair path's routine, the edge values) -- its loads and LDS
+    accesses sit in front of the first DMA and end in a barrier, so they may be visible to hipcc --
     but from the first row request on the hand-counted protocol must be exactly the plain kernel's: the loop holds 4 ticks' worth
     of DMA and `vmcnt(4)` waits, one barrier, no other vmcnt wait, no memory / LDS instruction outside the inline asm."""
     text = _asm("pvrtc_kernels.hip", tmp_path)
@@ -159,8 +160,6 @@ def test_pvrtc_onepass_halo_kernel_keeps_the_ring_protocol(tmp_path):
     assert sum(bool(re.match(r"\s+s_barrier", l)) for l in walk) == 1
     tail = [re.sub(r"\s+", " ", l.strip()) for l in body[back + 1:] if "s_waitcnt" in l and "vmcnt" in l]
     assert tail == ["s_waitcnt vmcnt(0)"], tail
-    # the pre-pass: light (it morphs a few thousand blocks per texture), no scratch
-    assert _kernel_meta(text, "icamd_pvrtc2_halo_morph_kernel")["scratch"] == 0
 
 
 def test_pvrtc_onepass_kernel_plain_scan_build_still_compiles(tmp_path):
