@@ -103,9 +103,10 @@ constexpr bool etc1_wave_workgroups(int strategy) { return ICAMD_ETC1_WAVE_WORKG
 #define ICAMD_ETC1_XCD_COLUMNS 2
 #endif
 // blockIdx.x -> (tile column, wave of the tile) for one-wave workgroups; -> tile column for four-wave workgroups (wave unused)
+// (bx, gx: blockIdx.x and gridDim.x -- or any other (x, extent) pair a caller maps its workgroups to
+// index stands for)
 template <int COMPS, bool WAVE_WORKGROUPS>
-__device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t &tile_col, uint32_t &wave) {
-  const uint32_t bx = blockIdx.x, gx = gridDim.x;
+__device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t bx, uint32_t gx, uint32_t &tile_col, uint32_t &wave) {
   constexpr uint32_t kMode = ICAMD_ETC1_XCD_COLUMNS;
   if (WAVE_WORKGROUPS) {
     tile_col = bx >> 2;
@@ -137,27 +138,27 @@ __device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t &tile_col, uint3
   }
 }
 template <int STRATEGY, int COMPS>
-__device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
+__device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P, uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx) {
   if (etc1_wave_workgroups(STRATEGY)) {
   TileCoord t;
   const uint32_t cols = 1u << P.log2_tile_cols, rows = 256u >> P.log2_tile_cols;
   uint32_t tile_col, wave;
-  etc1_tile_of_workgroup<COMPS, true>(tile_col, wave);
+  etc1_tile_of_workgroup<COMPS, true>(bx, gx, tile_col, wave);
   const uint32_t vt = threadIdx.x + 64u * wave;
   t.lx = vt & (cols - 1u);
   t.ly = vt >> P.log2_tile_cols;
   t.bcol0 = tile_col * cols;
-  t.brow0 = (blockIdx.y + P.tile_row0) * rows;
+  t.brow0 = (by + P.tile_row0) * rows;
   t.bcol = t.bcol0 + t.lx;
   t.brow = t.brow0 + t.ly;
-  t.img = blockIdx.z;
+  t.img = bz;
   t.full = t.bcol0 + cols <= P.block_cols && t.brow0 + rows <= P.block_rows;
   t.interior = (t.bcol0 + cols) * 4u <= P.width && (t.brow0 + rows) * 4u <= P.height;
   t.valid = t.full || (t.bcol < P.block_cols && t.brow < P.block_rows);
   return t;
   }
   uint32_t tile_col, wave;
-  etc1_tile_of_workgroup<COMPS, false>(tile_col, wave);
+  etc1_tile_of_workgroup<COMPS, false>(bx, gx, tile_col, wave);
   TileCoord t = locate_tile<false>(P, tile_col);
   if (ICAMD_ETC1_WAVE_8X8 && P.log2_tile_cols == 4u) {
     const uint32_t tid = threadIdx.x;
@@ -171,8 +172,8 @@ __device__ __forceinline__ TileCoord etc1_locate_tile(const GridParams &P) {
 }
 
 template <int COMPS, int STRATEGY>
-__device__ __forceinline__ void etc1_encode_one(const GridParams &P) {
-  const TileCoord t = etc1_locate_tile<STRATEGY, COMPS>(P);
+__device__ __forceinline__ void etc1_encode_one(const GridParams &P, uint32_t bx, uint32_t by, uint32_t bz, uint32_t gx) {
+  const TileCoord t = etc1_locate_tile<STRATEGY, COMPS>(P, bx, by, bz, gx);
   if (STRATEGY == 3 || !ICAMD_ETC1_REGROUP) {
     if (!t.valid) return;
     uint32_t px[16];
@@ -297,7 +298,7 @@ extern "C" {
 // mixed tier, i.e. 3 waves per SIMD, which costs smooth / flat content 10-18 %)
 #define ICAMD_ETC1_KERNEL(name, comps, strategy)                                                                      \
   __global__ void __launch_bounds__(kThreadsPerWorkgroup) __attribute__((amdgpu_waves_per_eu(4))) name(GridParams P) { \
-    etc1_encode_one<comps, strategy>(P);                                                                              \
+    etc1_encode_one<comps, strategy>(P, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);                               \
   }
 ICAMD_ETC1_KERNEL(icamd_etc1_rgb888_kernel, 3, 2)        // kSmallerError (the reference's default)
 ICAMD_ETC1_KERNEL(icamd_etc1_rgba8_kernel, 4, 2)
@@ -355,6 +356,11 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
     const Kernel q = comps == 4 ? icamd_etc1_rgba8_quad_kernel : icamd_etc1_rgb888_quad_kernel;
     return launch_tiled(q, q, P, stream, 4u, 1, true, 4u);
   }
+  // (r06, measured and NOT shipped -- profiles/r06_ab_etc1_persistent.log: PERSISTENT waves, four one-wave workgroups per SIMD each
+  //  walking 1 / 4 096 of the launch's tile waves, to keep every slot filled on content whose per-wave cost varies (3.09 resident
+  //  waves per SIMD on smooth content against 3.86 on noise).  16-38 % SLOWER on every content, scrambled walk or not: the hardware
+  //  does not spread a grid that exactly fills the chip evenly -- 2.74 resident waves per SIMD, the late workgroups run alone at
+  //  the end -- and a work queue that would make late starters harmless needs a per-launch counter.  Removed.)
   const Kernel k = kernels[comps == 4 ? 1 : 0][strategy];
   return launch_tiled(k, k, P, stream, cap, 1, etc1_wave_workgroups(P.etc_strategy < 4u ? (int)P.etc_strategy : 2));
 }

@@ -5,11 +5,31 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "ic_device.h"
 
 namespace icamd {
 
 constexpr int kThreadsPerWorkgroup = 256;  // 4 waves; one 4x4 block per lane
+
+// Compute units of a device (cached per ordinal): launch shapes and time models count the workgroup slots of THIS device -- a
+// partitioned MI355X (CPX: 32 CUs per partition) or another part must not be taken for 256 CUs.  A wrong figure
+// costs time, never bytes.
+inline uint32_t device_compute_units(int dev) {
+  static std::atomic<uint32_t> cached[64];
+  if (dev >= 0 && dev < 64) {
+    const uint32_t c = cached[dev].load();
+    if (c) return c;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  if (dev >= 0 && dev < 64) cached[dev].store((uint32_t)cus);
+  return (uint32_t)cus;
+}
 
 // Tile shape for a block grid `block_cols` wide (GridParams::log2_tile_cols): the smallest power of two that covers
 // a block row, at most 256.

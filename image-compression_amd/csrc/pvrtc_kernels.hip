@@ -833,23 +833,6 @@ void read_path_env() {
     g_path_mode.store(mode);
   });
 }
-// Compute units of a device (cached per ordinal): the time model below counts the workgroup slots of THIS device -- a
-// partitioned MI355X (CPX: 32 CUs per partition) or another part must not be modelled as 256 CUs.  The model's
-// time constants stay the MI355X's: a wrong choice costs time, never bytes -- both paths write identical blocks.
-uint32_t device_compute_units(int dev) {
-  static std::atomic<uint32_t> cached[64];
-  if (dev >= 0 && dev < 64) {
-    const uint32_t c = cached[dev].load();
-    if (c) return c;
-  }
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-    (void)hipGetLastError();
-    cus = 256;
-  }
-  if (dev >= 0 && dev < 64) cached[dev].store((uint32_t)cus);
-  return (uint32_t)cus;
-}
 // Strip height of the one-pass kernel for n_images size^2 textures, or -1 where the morph + encode pair is the better choice.
 // Time model, fitted on an MI355X (profiles/r05_ab_pvrtc_onepass.log, within 5 % of every measured shape from 1 x 512^2 to
 // 16 x 4096^2): a workgroup of K-block strips takes 11 + 5.8 K us whatever its width (its waves walk K + 2 block rows at two

@@ -238,6 +238,19 @@ def test_pvrtc_onepass_halo_form_on_textures_wider_than_a_workgroup(pkg, pvrtc_a
         out = pkg.encode_device(T.PVRTC2, d, n, n, 4)
         torch.cuda.synchronize()
         assert out.cpu().numpy().tobytes() == want, (mode, sb)
+    # the halo form keeps nothing between kernels either (its prologue reduces the boundary columns itself): such a launch is
+    # captured into a HIP graph without a caller-owned workspace, like the plain one-pass kernel's
+    assert pkg.pvrtc_tune(2, -1)
+    gs = torch.cuda.Stream()
+    cap = torch.zeros(n * n // 4, dtype=torch.uint8, device="cuda")
+    with torch.cuda.stream(gs):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=gs):
+            assert pkg.encode_device(T.PVRTC2, d, n, n, 4, out=cap.view(1, -1), stream=gs) is not None
+        g.replay()
+        gs.synchronize()
+    assert cap.cpu().numpy().tobytes() == want
+    del g
     # two textures, padded image strides, destination 8 mod 16
     assert pkg.pvrtc_tune(2, 4)
     img2 = np.ascontiguousarray(img[::-1, ::-1])
