@@ -103,8 +103,7 @@ constexpr bool etc1_wave_workgroups(int strategy) { return ICAMD_ETC1_WAVE_WORKG
 #define ICAMD_ETC1_XCD_COLUMNS 2
 #endif
 // blockIdx.x -> (tile column, wave of the tile) for one-wave workgroups; -> tile column for four-wave workgroups (wave unused)
-// (bx, gx: blockIdx.x and gridDim.x -- or any other (x, extent) pair a caller maps its workgroups to
-// index stands for)
+// (bx, gx: blockIdx.x and gridDim.x)
 template <int COMPS, bool WAVE_WORKGROUPS>
 __device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t bx, uint32_t gx, uint32_t &tile_col, uint32_t &wave) {
   constexpr uint32_t kMode = ICAMD_ETC1_XCD_COLUMNS;
