@@ -10,7 +10,8 @@ for wl in dxt1_rgba8 dxt1_rgb888 dxt5_rgba8 etc1_rgb888 pvrtc2_rgba8; do
 done
 for s in 0 1 3; do python bench.py --steps 40 --warmup 5 --workload etc1_rgb888 --etc-strategy $s --no-cpu-baseline --no-host-api --no-sustained --no-single-image --no-live-traffic 2>/dev/null | tail -1 >> $O; done
 # the BASELINE presets exactly as the driver runs them (all legs: sustained, single image, clock, cpu baseline, host API)
-for cfg in c2 c3 c4 c5 c5_4bpp; do python bench.py --config $cfg --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O; done
+# (c5_8192, r06: config 5's codec on 8192^2 textures = the one-pass kernel's halo form; --no-next-rows: the full next-row run follows below)
+for cfg in c2 c3 c4 c5 c5_8192 c5_4bpp; do python bench.py --config $cfg --steps 20 --warmup 5 --no-next-rows 2>/dev/null | tail -1 >> $O; done
 python - <<'PY'
 import json
 for l in open("gpurun_out/bench_all.jsonl"):

@@ -180,6 +180,31 @@ try:
                 print("MISMATCH pvrtc one-pass", n, cnt, sb, i)
 finally:
     pkg.pvrtc_tune(0, -1)
+# r06: the one-pass kernel's HALO form -- regions of one texture (the multi-GPU split, sharding.pvrtc_region) at least 64 block
+# columns wide, forced with a random strip height; the region is encoded from the WHOLE texture here (the GPU tier checks that
+# nothing outside region + ring is read), random world size, every rank's bytes against the oracle's range
+from image_compression_amd import sharding as _sh
+halo = 0
+try:
+    for it in range(max(4, n_seeds // 2)):
+        n = int(g.choice([512, 1024, 1024, 2048, 2048, 4096]))
+        img = T.soak_image(g, n, n, 4)
+        want = T.oracle_encode(T.PVRTC2, img, n, n, 4, threads=16)
+        d = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+        world = int(g.choice([1, 2, 4, 8, 16]))
+        pkg.pvrtc_tune(2, int(g.integers(2, 7)))
+        for rank in range(world):
+            r = _sh.pvrtc_region(n, world, rank)
+            if r["blocks_w"] < 64 or r["blocks_h"] < 4:
+                continue
+            out = pkg.pvrtc_encode_region_device(d, n, r["first_block"], r["n_blocks"])
+            torch.cuda.synchronize()
+            halo += 1
+            if out.cpu().numpy().tobytes() != want[r["dst_offset_bytes"]:r["dst_offset_bytes"] + r["dst_bytes"]]:
+                bad += 1
+                print("MISMATCH pvrtc halo form", n, world, rank)
+finally:
+    pkg.pvrtc_tune(0, -1)
 four = 0
 for it in range(8 * n_seeds):
     n = 1 << int(g.integers(3, 10))
@@ -190,5 +215,5 @@ for it in range(8 * n_seeds):
     if out.cpu().numpy().tobytes() != T.oracle_encode(T.PVRTC4, img, n, n, 4):
         bad += 1
         print("MISMATCH pvrtc4 (extension)", n, it)
-print("pvrtc one-pass soak: %d textures; pvrtc4 (extension) soak: %d textures; %d mismatches in total, %.1f s" % (one, four, bad, time.time() - t0))
+print("pvrtc one-pass soak: %d textures; halo-form regions: %d; pvrtc4 (extension) soak: %d textures; %d mismatches in total, %.1f s" % (one, halo, four, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
