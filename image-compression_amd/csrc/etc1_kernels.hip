@@ -359,7 +359,10 @@ hipError_t launch_etc1(int comps, const GridParams &P, hipStream_t stream) {
   //  walking 1 / 4 096 of the launch's tile waves, to keep every slot filled on content whose per-wave cost varies (3.09 resident
   //  waves per SIMD on smooth content against 3.86 on noise).  16-38 % SLOWER on every content, scrambled walk or not: the hardware
   //  does not spread a grid that exactly fills the chip evenly -- 2.74 resident waves per SIMD, the late workgroups run alone at
-  //  the end -- and a work queue that would make late starters harmless needs a per-launch counter.  Removed.)
+  //  the end -- and a work queue that would make late starters harmless needs a per-launch counter.  Removed.
+  //  Second form: k = 2 / 4 / 8 tile waves per one-wave workgroup, taken from k distant places of the launch, the grid still many
+  //  times the chip: c4 smooth + 5 % at k = 4 (182 -> 192 Gpixel/s: averaging the content does refill the slots), but the loop costs
+  //  the search 2.3 % on noise and 3.5 % on flat content (24 bytes of scratch, 106 SGPRs) and 16 x 4096^2 smooth loses 2.5 %.  Removed.)
   const Kernel k = kernels[comps == 4 ? 1 : 0][strategy];
   return launch_tiled(k, k, P, stream, cap, 1, etc1_wave_workgroups(P.etc_strategy < 4u ? (int)P.etc_strategy : 2));
 }
