@@ -591,17 +591,28 @@ class RcclGather:
     into rank `root`'s HBM).  torch.distributed is only used to hand rank 0's ncclUniqueId to the other ranks (any transport
     would do: the C entry points take the 128 bytes); the communicator and the collective are the library's."""
 
-    def __init__(self, rank, world, broadcast_bytes):
-        """broadcast_bytes(bytes or None) -> bytes: hands rank 0's argument to every rank (collective)."""
+    def __init__(self, rank, world, broadcast_bytes, agree=None):
+        """broadcast_bytes(bytes or None) -> bytes: hands rank 0's argument to every rank (collective).
+        agree(bool) -> bool: True iff every rank passed True (collective; None in a world of one rank).  Every rank makes the SAME
+        sequence of collective calls whatever fails where -- a rank without librccl, or rank 0 without an id, must not leave the
+        others waiting inside ncclCommInitRank."""
         L = lib()
-        if not L.icamd_rccl_available():
-            raise BackendError("librccl could not be bound: %s" % L.icamd_last_error().decode())
+        agree = agree or (lambda ok: ok)
         self.rank, self.world = rank, world
         self.comm = ctypes.c_void_p()
+        available = bool(L.icamd_rccl_available())
+        why = None if available else "librccl could not be bound: %s" % L.icamd_last_error().decode()
         uid = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
-        if rank == 0:
-            _check(L.icamd_rccl_get_unique_id(uid), "icamd_rccl_get_unique_id")
+        if rank == 0 and available:
+            st = L.icamd_rccl_get_unique_id(uid)
+            if st != OK:
+                available, why = False, "icamd_rccl_get_unique_id failed with status %d: %s" % (st, L.icamd_last_error().decode())
+                uid = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
         raw = broadcast_bytes(bytes(uid) if rank == 0 else None)
+        if available and not any(raw):
+            available, why = False, "rank 0 could not create an ncclUniqueId"
+        if not agree(available):
+            raise BackendError(why or "another rank cannot use librccl")
         uid = (ctypes.c_uint8 * RCCL_UNIQUE_ID_BYTES)(*raw)
         st = L.icamd_rccl_comm_init(ctypes.byref(self.comm), world, rank, uid)
         if st != OK:

@@ -126,7 +126,16 @@ def make_rccl_gather(pkg, rank, world, device):
         if world > 1 or _force_collectives():
             dist.broadcast(t, src=0)
         return bytes(t.cpu().numpy().tobytes())
-    return pkg.RcclGather(rank, world, broadcast_bytes)
+
+    def agree(ok):
+        if not (world > 1 or _force_collectives()):
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if on_device:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+    return pkg.RcclGather(rank, world, broadcast_bytes, agree)
 
 
 def gather_to_root(local, bufs, counts, rank, dst=0, group=None, host_staged=False, rccl=None):

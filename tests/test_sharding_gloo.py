@@ -229,3 +229,34 @@ def test_bench_slab_mode_over_gloo(world):
         results = mgr.dict()
         mp.spawn(_slab_worker, args=(world, port, results), nprocs=world, join=True)
         assert dict(results) == {r: 1 for r in range(world)}
+
+
+def _rccl_setup_worker(rank, world, port, results):
+    """r06: sharding.make_rccl_gather on ranks WITHOUT a GPU -- every rank must come out of it with the same exception after the
+    same sequence of collectives (id broadcast, agreement), none left waiting inside ncclCommInitRank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ic_amd_loader
+    pkg = ic_amd_loader.load_package()
+    sh = _load_sharding()
+    try:
+        sh.make_rccl_gather(pkg, rank, world, torch.device("cpu"))
+        outcome = "created"
+    except pkg.BackendError as e:
+        outcome = "BackendError"
+    # still in step: one more collective after the failed set-up must complete on every rank
+    flag = torch.tensor([1 if outcome == "BackendError" else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    results[rank] = (outcome, int(flag.item()))
+    dist.destroy_process_group()
+
+
+def test_rccl_gather_setup_fails_in_step_on_every_rank_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the set-up would succeed (covered by the gpu tier)")
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_rccl_setup_worker, args=(2, port, results), nprocs=2, join=True)
+        assert dict(results) == {0: ("BackendError", 1), 1: ("BackendError", 1)}
