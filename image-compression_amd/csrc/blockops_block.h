@@ -108,6 +108,15 @@ ICAMD_DEV void store_downsampled(const uint32_t src[16], int tr, int tc, uint32_
 // (color_util.h:335-380): (a + b + c + d) / 4 per channel, truncating.
 //
 // Palette planes of the colour block whose first dword is w0 (c0 | c1 << 16).  always4 = DXT5's colour block.
+// floor(n / 3) for n <= 765 = 3 * 255 is byte 2 of (85 n + 1) * 257: 85 * 257 = 65535 / 3, so the product is n / 3 in units of
+// 2^16 minus n / 3 plus 257 -- the + 1 keeps exact multiples of three from falling one short.  Checked for every n.
+constexpr bool third_is_byte2_of_product() {
+  for (unsigned n = 0; n <= 765; ++n)
+    if (((((85u * n + 1u) * 257u) >> 16) & 0xffu) != n / 3u || (85u * n + 1u) * 257u >= (1u << 24)) return false;
+  return true;
+}
+static_assert(third_is_byte2_of_product(), "(85 n + 1) * 257 >> 16 != n / 3");
+
 ICAMD_DEV void dxt_palette_planes(uint32_t w0, bool always4, uint32_t P[3]) {
   // ExtendToRgb888 (color_util.h:232-236) on both endpoints at once: X0 | X1 << 16 per channel
   const uint32_t r = (w0 >> 11) & 0x001f001fu, g = (w0 >> 5) & 0x003f003fu, b = w0 & 0x001f001fu;
@@ -115,11 +124,16 @@ ICAMD_DEV void dxt_palette_planes(uint32_t w0, bool always4, uint32_t P[3]) {
   const uint32_t c0 = w0 & 0xffffu, c1 = w0 >> 16;
   ICAMD_UNROLL
   for (int ch = 0; ch < 3; ++ch) {
-    const uint32_t x0 = X[ch] & 0xffu, x1 = bfe(X[ch], 16, 8);  // (the right shifts leak endpoint 1's low bits into bits 8-15)
-    // (2 a + b) / 3 and (a + 2 b) / 3 (CombineUint8Fast, color_util.h:288-291); c0 == c1 gives x2 = x3 = x1, which is
-    // what the decoder's special case for equal endpoints produces (dxtc.cc:184-186)
-    const uint32_t x2 = div3(umad24(x0, 2u, x1)), x3 = div3(umad24(x1, 2u, x0));
-    P[ch] = x0 | x1 << 8 | x2 << 16 | x3 << 24;
+    // X[ch]: endpoint 0 in byte 0, endpoint 1 in byte 2 (the right shifts leak endpoint 1's low bits into byte 1: every use
+    // below gives that byte the weight zero).  (2 a + b) / 3 and (a + 2 b) / 3 (CombineUint8Fast, color_util.h:288-291) *(r06)*:
+    // 85 (2 a + b) + 1 is ONE v_dot4 with the weights (170, 85) and the accumulator 1, times 257 one v_lshl_add, and the third
+    // is byte 2 of that (third_is_byte2_of_product) -- which a v_perm picks up while it assembles the plane: 6 instructions per
+    // channel where the multiply-shift form took 11.  c0 == c1 gives x2 = x3 = x1, which is what the decoder's special case for
+    // equal endpoints produces (dxtc.cc:184-186)
+    const uint32_t t2 = udot4(X[ch], 0x005500aau, 1u), t3 = udot4(X[ch], 0x00aa0055u, 1u);
+    const uint32_t p2 = (t2 << 8) + t2, p3 = (t3 << 8) + t3;
+    const uint32_t q = perm(p3, p2, 0x0c0c0602u);      // [x2, x3, 0, 0]
+    P[ch] = perm(q, X[ch], 0x05040200u);               // [x0, x1, x2, x3]
   }
   // DXT1's three-colour mode (c0 < c1): entry 2 = (a + b) / 2, entry 3 = black (dxtc.cc:187-193).  Our own encoder emits
   // it only from the constant-colour path; a wave without such a block skips this.
@@ -143,33 +157,47 @@ ICAMD_DEV uint32_t dxt_quad_selector(uint32_t t) {
 
 // Sum / 4 of the quad's four palette entries, packed R | G << 8 | B << 16 (byte 3 = 0).
 ICAMD_DEV uint32_t dxt_quad_average(const uint32_t P[3], uint32_t sel) {
-  const uint32_t sr = sad_u8(perm(P[0], P[0], sel), 0u, 0u);
-  const uint32_t tg = udot4(perm(P[1], P[1], sel), 0x40404040u, 0u);  // 64 * sum: (sum / 4) << 8 after masking
+  // 64 * (sum of the four values) has sum / 4 in byte 1 (sum <= 1020: nothing reaches byte 2); two v_perm collect the three
+  // bytes (r06: 2 instructions where masks, shifts and ors took 5)
+  const uint32_t tr = udot4(perm(P[0], P[0], sel), 0x40404040u, 0u);
+  const uint32_t tg = udot4(perm(P[1], P[1], sel), 0x40404040u, 0u);
   const uint32_t tb = udot4(perm(P[2], P[2], sel), 0x40404040u, 0u);
-  return ((tb & 0xff00u) << 8) | (tg & 0xff00u) | (sr >> 2);
+  return perm(tb, perm(tg, tr, 0x0c0c0501u), 0x0c050100u);
 }
 
 // The eight alpha values of a DXT5 alpha block (first dword w0 = a0 | a1 << 8 | codes...) as two dwords of bytes
 // (DecodeAlphaValues, dxtc.cc:195-217).
+// floor(n / 7) for n <= 7 * 255 and floor(n / 5) for n <= 5 * 255 as BYTE 2 of one 24-bit product (9363 = ceil(2^16 / 7),
+// 13108 = ceil(2^16 / 5)): no shift -- a v_perm picks the byte up while it assembles the table.  Checked for every n.
+constexpr bool quotient_is_byte2(unsigned d, unsigned mul, unsigned max) {
+  for (unsigned n = 0; n <= max; ++n)
+    if ((((n * mul) >> 16) & 0xffu) != n / d || n * mul >= (1u << 24)) return false;
+  return true;
+}
+static_assert(quotient_is_byte2(7, 9363, 1785) && quotient_is_byte2(5, 13108, 1275), "sevenths / fifths as byte 2 of a 24-bit product");
+
 ICAMD_DEV void dxt5_alpha_planes(uint32_t w0, uint32_t &tlo, uint32_t &thi) {
   const uint32_t a0 = w0 & 0xffu, a1 = (w0 >> 8) & 0xffu;
   const bool eight = a0 > a1;
   uint32_t lo8 = 0, hi8 = 0, lo6 = 0, hi6 = 0;
+  // *(r06)* (7 - k) a0 + k a1 is ONE v_dot4 on the block's first dword (a0, a1 in bytes 0, 1; the code bytes get weight zero),
+  // the division one 24-bit multiply whose byte 2 is the quotient: 2 instructions per value where two mads, a multiply and a
+  // shift took 4, and the table is assembled by v_perm (5 / 4 instead of 6 / 5 shifts and ors)
   if (!wave_all(!eight)) {  // some lane interpolates six values in sevenths
-    uint32_t t[8];
-    t[0] = a0; t[1] = a1;
+    uint32_t p[7];
     ICAMD_UNROLL
-    for (int k = 1; k <= 6; ++k) t[1 + k] = div7(umad24(a0, (uint32_t)(7 - k), umad24(a1, (uint32_t)k, 0u)));
-    lo8 = t[0] | t[1] << 8 | t[2] << 16 | t[3] << 24;
-    hi8 = t[4] | t[5] << 8 | t[6] << 16 | t[7] << 24;
+    for (int k = 1; k <= 6; ++k) p[k] = umad24(udot4(w0, (uint32_t)(k << 8 | (7 - k)), 0u), 9363u, 0u);  // byte 2 = value 1 + k
+    const uint32_t v23 = perm(p[2], p[1], 0x0c0c0602u);
+    lo8 = perm(v23, w0, 0x05040100u);                                  // [a0, a1, t2, t3]
+    hi8 = perm(perm(p[6], p[5], 0x06020c0cu), perm(p[4], p[3], 0x0c0c0602u), 0x07060100u);  // [t4, t5, t6, t7]
   }
   if (!wave_all(eight)) {   // some lane interpolates four values in fifths, then 0 and 255
-    uint32_t t[6];
-    t[0] = a0; t[1] = a1;
+    uint32_t p[5];
     ICAMD_UNROLL
-    for (int k = 1; k <= 4; ++k) t[1 + k] = div5(umad24(a0, (uint32_t)(5 - k), umad24(a1, (uint32_t)k, 0u)));
-    lo6 = t[0] | t[1] << 8 | t[2] << 16 | t[3] << 24;
-    hi6 = t[4] | t[5] << 8 | 0xff000000u;  // t[6] = 0, t[7] = 255
+    for (int k = 1; k <= 4; ++k) p[k] = umad24(udot4(w0, (uint32_t)(k << 8 | (5 - k)), 0u), 13108u, 0u);
+    const uint32_t v23 = perm(p[2], p[1], 0x0c0c0602u);
+    lo6 = perm(v23, w0, 0x05040100u);
+    hi6 = perm(p[4], p[3], 0x0c0c0602u) | 0xff000000u;  // [t4, t5, 0, 255]
   }
   tlo = eight ? lo8 : lo6;
   thi = eight ? hi8 : hi6;
@@ -211,8 +239,8 @@ ICAMD_DEV void dxt_downsample_2x2(const uint32_t *const s[2][2], uint32_t px[16]
           const uint32_t h = qy ? hi24 : lo24;
           const uint32_t a0 = udot4(perm(thi, tlo, dxt5_quad_alpha_selector<0>(h)), 0x40404040u, 0u);
           const uint32_t a1 = udot4(perm(thi, tlo, dxt5_quad_alpha_selector<1>(h)), 0x40404040u, 0u);
-          q0 |= (a0 & 0xff00u) << 16;
-          q1 |= (a1 & 0xff00u) << 16;
+          q0 = perm(a0, q0, 0x05020100u);  // byte 3 <- byte 1 of 64 * sum = sum / 4
+          q1 = perm(a1, q1, 0x05020100u);
         }
         // StoreDownsampledPixels4x4 (pixel4x4.h:152-162): block (i, j) fills the 2x2 quadrant at (2 i, 2 j)
         px[4 * (2 * i + qy) + 2 * j] = q0;
