@@ -98,18 +98,11 @@ __device__ __forceinline__ void pad_one(const BlockOpParams &P, uint32_t k) {
 // kSmallerError search is not carried along by a kHeuristic downsample and vice versa); ignored for DXT.
 // QUAD (ETC1 kSmallerError, small grids -- the low levels of a mip chain): work item k = 4 * output block + quad lane; the four
 // lanes build the same sixteen pixels and split the re-encode's searches (etc1_block.h encode_etc1_block_quad).
+// (img, r, c): image of a batched launch and the output block's position in its grid; kk = r * out_cols + c
 template <int CODEC, int STRATEGY, bool QUAD = false>
-__device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t k, BlockStash &stash) {
+__device__ __forceinline__ void downsample_at(const BlockOpParams &P, uint32_t img, uint32_t r, uint32_t c, uint32_t kk,
+                                              uint32_t quad_lane, BlockStash &stash) {
   constexpr int W = kWords(CODEC);
-  const uint32_t quad_lane = QUAD ? (k & 3u) : 0u;
-  if (QUAD) k >>= 2;
-  // image of a batched launch, then (r, c) inside its output grid
-  uint32_t img = 0, kk = k;
-  if (P.n_images > 1) {
-    img = fastdiv(k, P.div_out_per_image);
-    kk = k - img * P.out_per_image;
-  }
-  const uint32_t r = fastdiv(kk, P.div_out_cols), c = kk - r * P.out_cols;
   const uint32_t *src = reinterpret_cast<const uint32_t *>(P.src + (size_t)img * P.src_image_stride);
   uint32_t px[16], tmp[16];
   if (P.in_rows > 1 && P.in_cols > 1) {  // DownsampleBlocks2x2
@@ -185,6 +178,19 @@ __device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t 
   if (W == 4) store_stream16(dst, out[0], out[1], out[2], out[3]);
   else store_stream8(dst, out[0], out[1]);
 }
+// work item k of a linear launch -> (image, row, column) by two multiply-high divisions
+template <int CODEC, int STRATEGY, bool QUAD = false>
+__device__ __forceinline__ void downsample_one(const BlockOpParams &P, uint32_t k, BlockStash &stash) {
+  const uint32_t quad_lane = QUAD ? (k & 3u) : 0u;
+  if (QUAD) k >>= 2;
+  uint32_t img = 0, kk = k;
+  if (P.n_images > 1) {
+    img = fastdiv(k, P.div_out_per_image);
+    kk = k - img * P.out_per_image;
+  }
+  const uint32_t r = fastdiv(kk, P.div_out_cols), c = kk - r * P.out_cols;
+  downsample_at<CODEC, STRATEGY, QUAD>(P, img, r, c, kk, quad_lane, stash);
+}
 
 // Lanes per workgroup: the kernels that run an ETC1 codeword SEARCH per output block (Downsample and the Pad border with
 // kSplitHorizontally / kSplitVertically / kSmallerError) are launched as one-wave workgroups like the encoders (r05,
@@ -209,6 +215,18 @@ constexpr int blockop_lanes(int codec, int strategy, int part) {
     if (k < P.total_out) downsample_one<CODEC, STRATEGY>(P, k, stash);                                         \
   }
 
+// ROW TILES (r06; grids of at least 256 output columns, DXT and ETC1 kHeuristic): blockIdx = (column tile, output row, image),
+// so image and row are workgroup-uniform -- the two multiply-high divisions, their quarter-rate multiplies back and the 64-bit
+// row addressing move to the scalar unit, a lane adds a 32-bit column offset (the encoders' tile form).
+#define ICAMD_DOWNSAMPLE_ROWS_KERNEL(NAME, CODEC, STRATEGY)                                                    \
+  extern "C" __global__ void __launch_bounds__(kThreadsPerWorkgroup)                                           \
+  icamd_downsample_##NAME##_rows_kernel(BlockOpParams P) {                                                     \
+    __shared__ uint32_t lds_px[CODEC == ICAMD_ETC1 ? 1 : 4][CODEC == ICAMD_ETC1 ? 1 : kThreadsPerWorkgroup][4]; \
+    BlockStash stash;                                                                                          \
+    stash.base = CODEC == ICAMD_ETC1 ? &lds_px[0][0][0] : &lds_px[0][threadIdx.x][0];                          \
+    const uint32_t c = blockIdx.x * kThreadsPerWorkgroup + threadIdx.x, r = blockIdx.y, img = blockIdx.z;      \
+    if (c < P.out_cols) downsample_at<CODEC, STRATEGY>(P, img, r, c, r * P.out_cols + c, 0u, stash);           \
+  }
 ICAMD_PAD_KERNEL(dxt1, ICAMD_DXT1, 0, 0)
 ICAMD_PAD_KERNEL(dxt5, ICAMD_DXT5, 0, 0)
 ICAMD_PAD_KERNEL(etc1_copy, ICAMD_ETC1, 0, 1)
@@ -234,6 +252,9 @@ ICAMD_DOWNSAMPLE_KERNEL(etc1_split_h, ICAMD_ETC1, 0)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_split_v, ICAMD_ETC1, 1)
 ICAMD_DOWNSAMPLE_KERNEL(etc1, ICAMD_ETC1, 2)  // kSmallerError (and every value the reference's default: label maps to it)
 ICAMD_DOWNSAMPLE_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
+ICAMD_DOWNSAMPLE_ROWS_KERNEL(dxt1, ICAMD_DXT1, 0)
+ICAMD_DOWNSAMPLE_ROWS_KERNEL(dxt5, ICAMD_DXT5, 0)
+ICAMD_DOWNSAMPLE_ROWS_KERNEL(etc1_heuristic, ICAMD_ETC1, 3)
 // kSmallerError on grids of at most kDownsampleQuadMaxBlocks output blocks (r05): four lanes per output block.  A 512^2 level is
 // 4 096 output blocks = 64 waves of ~3 000 dependent instructions on 64 of 1 024 SIMDs; the quad form makes it 256 waves of ~1 500.
 constexpr uint32_t kDownsampleQuadMaxBlocks = 36864;
@@ -296,9 +317,20 @@ hipError_t launch_pad(int codec, const BlockOpParams &P, hipStream_t stream) {
 hipError_t launch_downsample(int codec, const BlockOpParams &P, hipStream_t stream) {
   if (P.total_out == 0) return hipSuccess;
   const dim3 grid((P.total_out + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup), block(kThreadsPerWorkgroup);
-  if (codec == ICAMD_DXT1) hipLaunchKernelGGL(icamd_downsample_dxt1_kernel, grid, block, 0, stream, P);
-  else if (codec == ICAMD_DXT5) hipLaunchKernelGGL(icamd_downsample_dxt5_kernel, grid, block, 0, stream, P);
-  else if (codec == ICAMD_ETC1) {
+  // row tiles where a row fills a workgroup (ICAMD_DOWNSAMPLE_ROW_TILES=0 keeps the linear launch for the A/B)
+  static const bool row_tiles_on = [] { const char *e = getenv("ICAMD_DOWNSAMPLE_ROW_TILES"); return !(e && e[0] == '0'); }();
+  const bool rows = row_tiles_on && P.in_rows > 1 && P.in_cols > 1 && P.out_cols >= (uint32_t)kThreadsPerWorkgroup &&
+                    P.out_rows <= 65535u && P.n_images <= 65535u;
+  const dim3 rgrid((P.out_cols + kThreadsPerWorkgroup - 1) / kThreadsPerWorkgroup, P.out_rows, P.n_images);
+  if (codec == ICAMD_DXT1) {
+    if (rows) hipLaunchKernelGGL(icamd_downsample_dxt1_rows_kernel, rgrid, block, 0, stream, P);
+    else hipLaunchKernelGGL(icamd_downsample_dxt1_kernel, grid, block, 0, stream, P);
+  } else if (codec == ICAMD_DXT5) {
+    if (rows) hipLaunchKernelGGL(icamd_downsample_dxt5_rows_kernel, rgrid, block, 0, stream, P);
+    else hipLaunchKernelGGL(icamd_downsample_dxt5_kernel, grid, block, 0, stream, P);
+  } else if (codec == ICAMD_ETC1 && P.etc_strategy == 3u && rows) {
+    hipLaunchKernelGGL(icamd_downsample_etc1_heuristic_rows_kernel, rgrid, block, 0, stream, P);
+  } else if (codec == ICAMD_ETC1) {
     const uint32_t lanes = (uint32_t)blockop_lanes(ICAMD_ETC1, P.etc_strategy == 3u ? 3 : 2, 0);
     const dim3 egrid((P.total_out + lanes - 1) / lanes), eblock(lanes);
     if (P.etc_strategy == 0u) hipLaunchKernelGGL(icamd_downsample_etc1_split_h_kernel, egrid, eblock, 0, stream, P);
