@@ -104,21 +104,22 @@ constexpr bool etc1_wave_workgroups(int strategy) { return ICAMD_ETC1_WAVE_WORKG
 #endif
 // blockIdx.x -> (tile column, wave of the tile) for one-wave workgroups; -> tile column for four-wave workgroups (wave unused)
 // (bx, gx: blockIdx.x and gridDim.x)
-// ICAMD_ETC1_ROTATE_ROWS (r06, one-wave workgroups): the order in which an XCD's workgroups of a tile row take its tiles is ROTATED by
+// ICAMD_ETC1_ROTATE_ROWS (r06): the order in which an XCD's workgroups of a tile row take its tiles is ROTATED by
 // the row (+ image) index.  An XCD's workgroups are dealt to its shader engines in a fixed rotation too (XCD-local index mod 4), and
 // with 8 workgroups per XCD and tile row (config c4: 1024^2 textures) that made engine e the owner of tiles q = e, e + 4 of EVERY
 // row: a static partition of the image by column, which a gradient along the row loads unequally -- the same effect the coarse XCD
 // groupings showed (profiles/r06_ab_etc1_xcd.log), one level down.  SQ / SPI counters: 3.09 resident waves per SIMD on smooth
 // content with room in the SIMDs (profiles/r06_valu_counters.txt).  With the rotation every engine sees every column within four
 // rows: c4 smooth 182 -> 194 Gpixel/s, noise / flat / 16 x 4096^2 (32 workgroups per XCD and row: already spread) unchanged
-// (profiles/r06_ab_etc1_rotate.log).  Four scalar instructions, any extent of at least four such tiles; bx mod 8 -- the XCD -- is kept.
+// (profiles/r06_ab_etc1_rotate.log; kHeuristic's four-wave workgroups, 4096-px rows = 8 per XCD and row: smooth + 2 %, 2048^2 + 3-6 %).
+// Four scalar instructions, any extent of at least four such tiles; bx mod 8 -- the XCD -- is kept.
 #ifndef ICAMD_ETC1_ROTATE_ROWS
 #define ICAMD_ETC1_ROTATE_ROWS 1
 #endif
 template <int COMPS, bool WAVE_WORKGROUPS>
 __device__ __forceinline__ void etc1_tile_of_workgroup(uint32_t bx, uint32_t gx, uint32_t &tile_col, uint32_t &wave, uint32_t by = 0u) {
   constexpr uint32_t kMode = ICAMD_ETC1_XCD_COLUMNS;
-  if (ICAMD_ETC1_ROTATE_ROWS && (WAVE_WORKGROUPS || ICAMD_ETC1_ROTATE_ROWS == 2) && (gx & 7u) == 0u && gx >= 32u) {
+  if (ICAMD_ETC1_ROTATE_ROWS && (gx & 7u) == 0u && gx >= 32u) {
     const uint32_t nq = gx >> 3;
     uint32_t q = (bx >> 3) + (by & 3u);  // (four engines: a rotation by row mod 4 is all it takes, and it needs no division)
     q -= q >= nq ? nq : 0u;
