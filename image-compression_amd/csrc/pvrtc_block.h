@@ -348,6 +348,55 @@ ICAMD_DEV void pvrtc_row_mods_pd(const uint32_t P0[4], const uint32_t D0[4], con
   }
 }
 
+// ---- the walk on 64-bit register pairs (r06) ----------------------------------------------------------------------------
+// The four sums of a walk are two (rb, ga) word pairs; as ONE 64-bit integer each -- word v at bits 32 (v & 1) -- a pair steps
+// with one v_lshl_add_u64 (4.4 clocks at two waves per SIMD against 2 x 3.5 for two v_add_u32 next to half-rate instructions:
+// scripts/ubench_u64.hip).  Exact: every quantity of the walk is a LINEAR function of the colours, 16-bit lanes of a word may be
+// negative on the way (steps, differences), so the whole chain is computed modulo 2^64 -- borrows cross the word boundary exactly
+// as they cross the lane boundary inside a word in the 32-bit form -- and the values that are READ (the sums at the pixels) have
+// all four lanes in 0 .. 65 280, so their words are the 32-bit form's words.
+// -DICAMD_PVRTC_WALK32 builds the 32-bit form (A/B; profiles/r06_ab_pvrtc_walk64.log: 16 x 4096^2 0.3887 -> 0.3769 ms).
+#if !defined(ICAMD_PVRTC_WALK32) && !defined(ICAMD_PVRTC_WALK64)
+#define ICAMD_PVRTC_WALK64 1
+#endif
+typedef unsigned long long icamd_u64;
+ICAMD_DEV icamd_u64 pack64(uint32_t lo, uint32_t hi) { return (icamd_u64)hi << 32 | lo; }
+// the pair of two SIGNED words (each below 2^31 in magnitude, given modulo 2^32) as hi * 2^32 + lo modulo 2^64
+ICAMD_DEV icamd_u64 pack64_signed(uint32_t lo, uint32_t hi) { return pack64(lo, hi + (uint32_t)((int32_t)lo >> 31)); }
+template <int S>
+ICAMD_DEV icamd_u64 shl_add64(icamd_u64 a, icamd_u64 b) {  // (a << S) + b, S = 0 .. 4
+  static_assert(S >= 0 && S <= 4, "v_lshl_add_u64 shifts by at most 4");
+#if defined(ICAMD_HOST_EMULATION) || !defined(ICAMD_PVRTC_WALK64_ASM)
+  return (a << S) + b;  // (hipcc selects v_lshl_add_u64 for it on gfx950 and, unlike after an asm, knows which hazards it has)
+#else
+  icamd_u64 r;
+  asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(r) : "v"(a), "v"(b), "n"(S));
+  return r;
+#endif
+}
+ICAMD_DEV icamd_u64 add64(icamd_u64 a, icamd_u64 b) { return shl_add64<0>(a, b); }
+// pvrtc_row_mods_pd with the bases as pairs: P*[p] = words (2 p, 2 p + 1) of the 32-bit form
+ICAMD_DEV void pvrtc_row_mods_pd64(const icamd_u64 P0[2], const icamd_u64 D0[2], const icamd_u64 P1[2], const icamd_u64 D1[2],
+                                   const uint32_t *pixels, uint32_t row[2]) {
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const icamd_u64 *Pb = h ? P1 : P0, *D = h ? D1 : D0;
+    icamd_u64 Q[2] = { Pb[0], Pb[1] };
+    uint32_t acc = 0;
+    ICAMD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t P[4] = { (uint32_t)Q[0], (uint32_t)(Q[0] >> 32), (uint32_t)Q[1], (uint32_t)(Q[1] >> 32) };
+      acc = opaque(accumulate_mod(pixels[4 * h + j], P, 1u << (8 * j), acc));
+      ICAMD_SCHED_FENCE();
+      if (j < 3) {
+        Q[0] = add64(Q[0], D[0]);
+        Q[1] = add64(Q[1], D[1]);
+      }
+    }
+    row[h] = acc;
+  }
+}
+
 template <bool WITH_RIGHT>
 ICAMD_DEV void pvrtc_row_mods(uint32_t yw, const PvrtcAB top[3], const PvrtcAB bot[3], const uint32_t *pixels,
                               uint32_t right_pixel, uint32_t row[2], uint32_t *right_mod) {
@@ -845,7 +894,36 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
         A[c][v] = b[v];
       }
     }
-#if !defined(ICAMD_PVRTC_ONEPASS_STEP_V)
+#if defined(ICAMD_PVRTC_WALK64)
+    // the same bases as 64-bit pairs (pvrtc_row_mods_pd64).  Set up word by word like the 32-bit form, then made exact modulo
+    // 2^64: the steps are SIGNED quantities below 2^31 in magnitude per word (lanes of at most 16 320), so the pair's high
+    // word owes the low word's sign -- hi + (lo >> 31, arithmetic); the P bases have non-negative lanes and need nothing.
+    icamd_u64 P0[2], D0[2], P1[2], D1[2], dP0[2], dD0[2], dP1[2], dD1[2];
+    {
+      uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        d0[v] = V[1][v] - V[0][v];        ed0[v] = dV[1][v] - dV[0][v];
+        p0[v] = (V[0][v] + V[1][v]) << 2; ep0[v] = (dV[0][v] + dV[1][v]) << 2;
+        d1[v] = V[2][v] - V[1][v];        ed1[v] = dV[2][v] - dV[1][v];
+        p1[v] = V[1][v] << 3;             ep1[v] = dV[1][v] << 3;
+      }
+      ICAMD_UNROLL
+      for (int p = 0; p < 2; ++p) {
+        P0[p] = pack64(p0[2 * p], p0[2 * p + 1]);  P1[p] = pack64(p1[2 * p], p1[2 * p + 1]);
+        D0[p] = pack64_signed(d0[2 * p], d0[2 * p + 1]);    D1[p] = pack64_signed(d1[2 * p], d1[2 * p + 1]);
+        dD0[p] = pack64_signed(ed0[2 * p], ed0[2 * p + 1]); dD1[p] = pack64_signed(ed1[2 * p], ed1[2 * p + 1]);
+        dP0[p] = pack64_signed(ep0[2 * p], ep0[2 * p + 1]); dP1[p] = pack64_signed(ep1[2 * p], ep1[2 * p + 1]);
+      }
+    }
+#define ICAMD_ROW_MODS(px_, row_) pvrtc_row_mods_pd64(P0, D0, P1, D1, px_, row_)
+#define ICAMD_ROW_STEP()                                                                                     \
+  ICAMD_UNROLL                                                                                               \
+  for (int p = 0; p < 2; ++p) {                                                                              \
+    P0[p] = add64(P0[p], dP0[p]); D0[p] = add64(D0[p], dD0[p]);                                              \
+    P1[p] = add64(P1[p], dP1[p]); D1[p] = add64(D1[p], dD1[p]);                                              \
+  }
+#elif !defined(ICAMD_PVRTC_ONEPASS_STEP_V)
     // ... and from them the bases of the horizontal walks and THEIR steps per pixel row (pvrtc_row_mods_pd; everything is
     // linear in the vertical weight, and sums / shifts commute modulo 2^32, so stepping these equals re-deriving them):
     //   left half row:  D = V[1] - V[0],  P = 4 (V[0] + V[1]);     right half row:  D = V[2] - V[1],  P = 8 V[1]
@@ -1090,6 +1168,27 @@ ICAMD_DEV uint32_t pvrtc4_row_bits(const uint32_t P0[4], const uint32_t D0[4], c
   }
   return udot4(acc, 0x40100401u, 0u);
 }
+// ... with the bases as 64-bit pairs (see pvrtc_row_mods_pd64)
+ICAMD_DEV uint32_t pvrtc4_row_bits64(const icamd_u64 P0[2], const icamd_u64 D0[2], const icamd_u64 P1[2], const icamd_u64 D1[2],
+                                     const uint32_t px[4]) {
+  uint32_t acc = 0;
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const icamd_u64 *Pb = h ? P1 : P0, *D = h ? D1 : D0;
+    icamd_u64 Q[2] = { Pb[0], Pb[1] };
+    ICAMD_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t P[4] = { (uint32_t)Q[0], (uint32_t)(Q[0] >> 32), (uint32_t)Q[1], (uint32_t)(Q[1] >> 32) };
+      acc = opaque(accumulate_mod(px[2 * h + j], P, 1u << (16 * h + 8 * j), acc));
+      ICAMD_SCHED_FENCE();
+      if (j == 0) {
+        Q[0] = add64(Q[0], D[0]);
+        Q[1] = add64(Q[1], D[1]);
+      }
+    }
+  }
+  return udot4(acc, 0x40100401u, 0u);
+}
 template <typename Tick, typename Lookup10, typename Exchange, typename BlockStore>
 ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tick, Lookup10 &lookup10, Exchange &exchange,
                                     BlockStore &store) {
@@ -1122,6 +1221,41 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
     exchange(s, cc[1], cc[0], cc[2]);
     // colour rows (s-1, s): V = 16 A + w * 4 (B - A) for weight w = 0..3; from it the walks' bases and their steps per pixel row:
     //   x = 0, 1: D = 4 (V[1] - V[0]), P = 8 (V[0] + V[1]);   x = 2, 3: D = 4 (V[2] - V[1]), P = 16 V[1]
+#if defined(ICAMD_PVRTC_WALK64)
+    icamd_u64 P0[2], D0[2], P1[2], D1[2], dP0[2], dD0[2], dP1[2], dD1[2];
+    {
+      uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        uint32_t Vc[3], dVc[3];
+        ICAMD_UNROLL
+        for (int c = 0; c < 3; ++c) {
+          const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
+          Vc[c] = A[c][v] << 4;
+          dVc[c] = (b - A[c][v]) << 2;
+          A[c][v] = b;
+        }
+        d0[v] = (Vc[1] - Vc[0]) << 2;   ed0[v] = (dVc[1] - dVc[0]) << 2;
+        p0[v] = (Vc[0] + Vc[1]) << 3;   ep0[v] = (dVc[0] + dVc[1]) << 3;
+        d1[v] = (Vc[2] - Vc[1]) << 2;   ed1[v] = (dVc[2] - dVc[1]) << 2;
+        p1[v] = Vc[1] << 4;             ep1[v] = dVc[1] << 4;
+      }
+      ICAMD_UNROLL
+      for (int p = 0; p < 2; ++p) {  // (signed steps: lanes of at most 16 320 -- see pvrtc_onepass_strip)
+        P0[p] = pack64(p0[2 * p], p0[2 * p + 1]);  P1[p] = pack64(p1[2 * p], p1[2 * p + 1]);
+        D0[p] = pack64_signed(d0[2 * p], d0[2 * p + 1]);    D1[p] = pack64_signed(d1[2 * p], d1[2 * p + 1]);
+        dD0[p] = pack64_signed(ed0[2 * p], ed0[2 * p + 1]); dD1[p] = pack64_signed(ed1[2 * p], ed1[2 * p + 1]);
+        dP0[p] = pack64_signed(ep0[2 * p], ep0[2 * p + 1]); dP1[p] = pack64_signed(ep1[2 * p], ep1[2 * p + 1]);
+      }
+    }
+#define ICAMD_ROW4_BITS(px_) pvrtc4_row_bits64(P0, D0, P1, D1, px_)
+#define ICAMD_ROW4_STEP()                                                                                    \
+  ICAMD_UNROLL                                                                                               \
+  for (int p = 0; p < 2; ++p) {                                                                              \
+    P0[p] = add64(P0[p], dP0[p]); D0[p] = add64(D0[p], dD0[p]);                                              \
+    P1[p] = add64(P1[p], dP1[p]); D1[p] = add64(D1[p], dD1[p]);                                              \
+  }
+#else
     uint32_t P0[4], D0[4], P1[4], D1[4], dP0[4], dD0[4], dP1[4], dD1[4];
     ICAMD_UNROLL
     for (int v = 0; v < 4; ++v) {
@@ -1138,15 +1272,17 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
       D1[v] = (Vc[2] - Vc[1]) << 2;   dD1[v] = (dVc[2] - dVc[1]) << 2;
       P1[v] = Vc[1] << 4;             dP1[v] = dVc[1] << 4;
     }
+#define ICAMD_ROW4_BITS(px_) pvrtc4_row_bits(P0, D0, P1, D1, px_)
 #define ICAMD_ROW4_STEP()                                                                            \
   ICAMD_UNROLL                                                                                       \
   for (int v = 0; v < 4; ++v) { P0[v] += dP0[v]; D0[v] += dD0[v]; P1[v] += dP1[v]; D1[v] += dD1[v]; }
-    if (s >= 1) data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 16;  // row 2 of block s-1, weight 0
+#endif
+    if (s >= 1) data |= ICAMD_ROW4_BITS(ep) << 16;  // row 2 of block s-1, weight 0
     ICAMD_ROW4_STEP()
     tick(4 * s + 4, mp, ep);
     pvrtc4_keys_row<0>(keys, mp);
     if (s >= 1) {  // row 3 of block s-1, weight 1: the block is complete
-      data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 24;
+      data |= ICAMD_ROW4_BITS(ep) << 24;
       store((uint32_t)(s - 1), data, own_acc);
     }
     if (s == K) break;
@@ -1155,13 +1291,14 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
     pvrtc4_keys_row<1>(keys, mp);
     if (s >= 0) {  // row 0 of block s, weight 2
       own_acc = cc[1];
-      data = pvrtc4_row_bits(P0, D0, P1, D1, ep);
+      data = ICAMD_ROW4_BITS(ep);
     }
     ICAMD_ROW4_STEP()
     tick(4 * s + 6, mp, ep);
     pvrtc4_keys_row<2>(keys, mp);
-    if (s >= 0) data |= pvrtc4_row_bits(P0, D0, P1, D1, ep) << 8;  // row 1 of block s, weight 3
+    if (s >= 0) data |= ICAMD_ROW4_BITS(ep) << 8;  // row 1 of block s, weight 3
 #undef ICAMD_ROW4_STEP
+#undef ICAMD_ROW4_BITS
   }
 }
 
