@@ -375,6 +375,12 @@ ICAMD_DEV icamd_u64 shl_add64(icamd_u64 a, icamd_u64 b) {  // (a << S) + b, S = 
 #endif
 }
 ICAMD_DEV icamd_u64 add64(icamd_u64 a, icamd_u64 b) { return shl_add64<0>(a, b); }
+ICAMD_DEV icamd_u64 opaque64(icamd_u64 v) {
+#if !defined(ICAMD_HOST_EMULATION)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 // pvrtc_row_mods_pd with the bases as pairs: P*[p] = words (2 p, 2 p + 1) of the 32-bit form
 ICAMD_DEV void pvrtc_row_mods_pd64(const icamd_u64 P0[2], const icamd_u64 D0[2], const icamd_u64 P1[2], const icamd_u64 D1[2],
                                    const uint32_t *pixels, uint32_t row[2]) {
@@ -761,12 +767,64 @@ ICAMD_DEV void pvrtc_encode_strip(uint32_t k_blocks, PixelRowLoader &load_px, Co
 // GetExtremesFast (pvrtc.cc:255-329) consumed one pixel row at a time: the same keys as pvrtc_extremes, the block's four
 // rows arriving in four calls (Q = row inside the block, compile-time), the ten data-dependent pixel look-ups of the final
 // scan batched into one call of `lookup10` (on the device: ten ds_read_b32 from the pixel-row ring under one wait).
+// The (rb, ga) "first maximum" keys as ONE running pair (r06).  The plain form is max over pixels p of k_p + up_p with
+// up_p = (N - 1 - 2 p) per 16-bit lane (N = 32 or 16 pixels): two word adds per pixel.  With M_p = (that maximum up to p) - up_p,
+//   M_0 = k_0,   M_p = max(M_(p-1) + 2, k_p)   per lane,
+// the SAME constant is added every time, to the running value instead of the new key -- so (M_rb, M_ga) steps as a 64-bit pair
+// with one v_lshl_add_u64 (see "the walk on 64-bit register pairs": at two waves per SIMD 4.4 clocks against 2 x 3.5).  Lanes
+// stay in 0 .. 65 280 + 2 N: M_p >= k_p >= 0 and the maximum is at most 65 280 + N - 1.  The keys the scan reads are
+// M_(N-1) + up_(N-1) = M - (N - 1) per lane (pvrtc_keys_max_words).  -DICAMD_PVRTC_KEYS_UP builds the plain form.
 struct PvrtcMorphKeys {
-  uint32_t min_l, max_l, min_rb, max_rb, min_ga, max_ga;
+  uint32_t min_l, max_l, min_rb, min_ga;
+#if defined(ICAMD_PVRTC_KEYS_UP)
+  uint32_t max_rb, max_ga;
+#else
+  icamd_u64 max_pair;  // M_rb | M_ga << 32; first assigned by pixel 0 of a block
+#endif
 };
 ICAMD_DEV void pvrtc_keys_reset(PvrtcMorphKeys &k) {
   k.min_l = k.min_rb = k.min_ga = 0xffffffffu;
-  k.max_l = k.max_rb = k.max_ga = 0u;
+  k.max_l = 0u;
+#if defined(ICAMD_PVRTC_KEYS_UP)
+  k.max_rb = k.max_ga = 0u;
+#else
+  k.max_pair = 0u;
+#endif
+}
+// one pixel's (rb, ga) keys into the running maxima; P = pixel index in the block (compile-time after unrolling), N = pixels
+template <int N>
+ICAMD_DEV void pvrtc_keys_max_step(PvrtcMorphKeys &k, int P, uint32_t k_rb, uint32_t k_ga) {
+#if defined(ICAMD_PVRTC_KEYS_UP)
+  const uint32_t up = (uint32_t)(N - 1 - 2 * P) * 0x00010001u;
+  k.max_rb = pk_max_u16(k.max_rb, k_rb + up);
+  k.max_ga = pk_max_u16(k.max_ga, k_ga + up);
+#else
+  if (P == 0) {
+    k.max_pair = pack64(k_rb, k_ga);
+  } else {
+    const icamd_u64 m = add64(k.max_pair, pack64(0x00020002u, 0x00020002u));
+    k.max_pair = pack64(pk_max_u16((uint32_t)m, k_rb), pk_max_u16((uint32_t)(m >> 32), k_ga));
+  }
+#endif
+}
+template <int N>
+ICAMD_DEV void pvrtc_keys_max_words(const PvrtcMorphKeys &k, uint32_t &max_rb, uint32_t &max_ga) {
+#if defined(ICAMD_PVRTC_KEYS_UP)
+  max_rb = k.max_rb;
+  max_ga = k.max_ga;
+#else
+  max_rb = (uint32_t)k.max_pair - (uint32_t)(N - 1) * 0x00010001u;
+  max_ga = (uint32_t)(k.max_pair >> 32) - (uint32_t)(N - 1) * 0x00010001u;
+#endif
+}
+ICAMD_DEV void pvrtc_keys_opaque(PvrtcMorphKeys &k) {
+  k.min_l = opaque(k.min_l); k.max_l = opaque(k.max_l);
+  k.min_rb = opaque(k.min_rb); k.min_ga = opaque(k.min_ga);
+#if defined(ICAMD_PVRTC_KEYS_UP)
+  k.max_rb = opaque(k.max_rb); k.max_ga = opaque(k.max_ga);
+#else
+  k.max_pair = opaque64(k.max_pair);
+#endif
 }
 template <int Q>
 ICAMD_DEV void pvrtc_keys_row(PvrtcMorphKeys &k, const uint32_t px[8]) {
@@ -778,29 +836,27 @@ ICAMD_DEV void pvrtc_keys_row(PvrtcMorphKeys &k, const uint32_t px[8]) {
       const int p = 8 * Q + x + q;
       const uint32_t c = px[x + q], i = (uint32_t)(p & 3);
       const uint32_t idx4 = (uint32_t)(p & ~3) * 0x01010101u + 0x03020100u;
-      const uint32_t up = (uint32_t)(31 - 2 * p) * 0x00010001u;
       kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
       const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16);
       const uint32_t k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
       k.min_rb = pk_min_u16(k.min_rb, k_rb);
       k.min_ga = pk_min_u16(k.min_ga, k_ga);
-      k.max_rb = pk_max_u16(k.max_rb, k_rb + up);
-      k.max_ga = pk_max_u16(k.max_ga, k_ga + up);
+      pvrtc_keys_max_step<32>(k, p, k_rb, k_ga);
     }
     const int p = 8 * Q + x;
     k.min_l = umin3(k.min_l, kl[0], kl[1]);
     k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(31 - 2 * p), kl[1] + (uint32_t)(31 - 2 * (p + 1)));
   }
-  k.min_l = opaque(k.min_l); k.max_l = opaque(k.max_l);
-  k.min_rb = opaque(k.min_rb); k.max_rb = opaque(k.max_rb);
-  k.min_ga = opaque(k.min_ga); k.max_ga = opaque(k.max_ga);
+  pvrtc_keys_opaque(k);
   ICAMD_SCHED_FENCE();
 }
 // lookup10(idx[10], out[10]): out[i] = pixel idx[i] (0..31, raster inside the block) of the block whose rows were just consumed
 template <typename Lookup10>
 ICAMD_DEV void pvrtc_keys_finish(const PvrtcMorphKeys &k, uint32_t image0, Lookup10 &lookup10, uint32_t &col_a, uint32_t &col_b) {
+  uint32_t max_rb, max_ga;
+  pvrtc_keys_max_words<32>(k, max_rb, max_ga);
   const uint32_t kmin[5] = { k.min_l, k.min_rb & 0xffffu, k.min_ga & 0xffffu, k.min_rb >> 16, k.min_ga >> 16 };
-  const uint32_t kmax[5] = { k.max_l, k.max_rb & 0xffffu, k.max_ga & 0xffffu, k.max_rb >> 16, k.max_ga >> 16 };
+  const uint32_t kmax[5] = { k.max_l, max_rb & 0xffffu, max_ga & 0xffffu, max_rb >> 16, max_ga >> 16 };
   uint32_t idx[10], v[10];
   ICAMD_UNROLL
   for (int i = 0; i < 5; ++i) {
@@ -1108,27 +1164,25 @@ ICAMD_DEV void pvrtc4_keys_row(PvrtcMorphKeys &k, const uint32_t px[4]) {
       const int p = 4 * Q + x + q;
       const uint32_t c = px[x + q], i = (uint32_t)(p & 3);
       const uint32_t idx4 = (uint32_t)(p & ~3) * 0x01010101u + 0x03020100u;
-      const uint32_t up = (uint32_t)(15 - 2 * p) * 0x00010001u;
       kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
       const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16), k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
       k.min_rb = pk_min_u16(k.min_rb, k_rb);
       k.min_ga = pk_min_u16(k.min_ga, k_ga);
-      k.max_rb = pk_max_u16(k.max_rb, k_rb + up);
-      k.max_ga = pk_max_u16(k.max_ga, k_ga + up);
+      pvrtc_keys_max_step<16>(k, p, k_rb, k_ga);
     }
     const int p = 4 * Q + x;
     k.min_l = umin3(k.min_l, kl[0], kl[1]);
     k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(15 - 2 * p), kl[1] + (uint32_t)(15 - 2 * (p + 1)));
   }
-  k.min_l = opaque(k.min_l); k.max_l = opaque(k.max_l);
-  k.min_rb = opaque(k.min_rb); k.max_rb = opaque(k.max_rb);
-  k.min_ga = opaque(k.min_ga); k.max_ga = opaque(k.max_ga);
+  pvrtc_keys_opaque(k);
   ICAMD_SCHED_FENCE();
 }
 template <typename Lookup10>
 ICAMD_DEV void pvrtc4_keys_finish(const PvrtcMorphKeys &k, uint32_t image0, Lookup10 &lookup10, uint32_t &col_a, uint32_t &col_b) {
+  uint32_t max_rb, max_ga;
+  pvrtc_keys_max_words<16>(k, max_rb, max_ga);
   const uint32_t kmin[5] = { k.min_l, k.min_rb & 0xffffu, k.min_ga & 0xffffu, k.min_rb >> 16, k.min_ga >> 16 };
-  const uint32_t kmax[5] = { k.max_l, k.max_rb & 0xffffu, k.max_ga & 0xffffu, k.max_rb >> 16, k.max_ga >> 16 };
+  const uint32_t kmax[5] = { k.max_l, max_rb & 0xffffu, max_ga & 0xffffu, max_rb >> 16, max_ga >> 16 };
   uint32_t idx[10], v[10];
   ICAMD_UNROLL
   for (int i = 0; i < 5; ++i) {
