@@ -581,7 +581,7 @@ ICAMD_DEV void pvrtc_encode_block_rows(RowLoader &load, const PvrtcColors nb[3][
 // right after row 0 of the block under it.  44 -> 36 + 8/K modulation values per block.
 struct PvrtcBlockAcc {
   uint32_t hc, vc, d1, d2;
-  uint32_t u01, u23;    // rows (0, 1) / (2, 3): byte x = m(x, y) | m(x + 4, y) << 2 | m(x, y + 1) << 4 | m(x + 4, y + 1) << 6
+  uint32_t u01, u23;    // rows (0, 1) / (2, 3): byte x = m(x, y) | m(x, y + 1) << 2 | m(x + 4, y) << 4 | m(x + 4, y + 1) << 6
   uint32_t col0, col7;  // EXCHANGE only: byte y = modulation of pixel (0, y) / (7, y) of the block
 };
 // one pixel row (y = 0..3, compile-time after unrolling) of a block: everything except the vertical differences.
@@ -604,18 +604,19 @@ ICAMD_DEV void pvrtc_acc_row(PvrtcBlockAcc &A, int y, const uint32_t row[2], uin
   } else {
     A.vc = sad_u8(row[1], alignbit(right_mod, row[1], 8), A.vc);
   }
-  // 1BPP word: bit 8y + x = m >> 1
-  const uint32_t twice = udot4(row[1] & 0x02020202u, 0x80402010u, udot4(row[0] & 0x02020202u, 0x08040201u, 0u));
+  // both half rows in one word (r06): byte x = m(x) | m(x + 4) << 4 (at most 51), so that ONE dot product per gather sees
+  // all eight values -- a weight w on byte x is w on m(x) and 16 w on m(x + 4), which is what both gathers want
+  const uint32_t u = row[0] | row[1] << 4;
+  // 1BPP word: bit 8y + x = m >> 1;  sum_x (2 hi(x) + 32 hi(x + 4)) 2^x = twice the row's eight bits
+  const uint32_t twice = udot4(u & 0x22222222u, 0x08040201u, 0u);
   A.d1 |= y == 0 ? twice >> 1 : twice << (8 * y - 1);
   // 2BPP word: the samples with (x ^ y) & 1 == 0, 2 bits each, raster order -> byte y
-  const uint32_t w0 = (y & 1) ? 0x04000100u : 0x00040001u, w1 = (y & 1) ? 0x40001000u : 0x00400010u;
-  A.d2 |= udot4(row[1], w1, udot4(row[0], w0, 0u)) << (8 * y);
-  // values 1 or 2 are counted at the end, two rows per dword
-  const uint32_t u = row[0] | row[1] << 2;
+  A.d2 |= udot4(u, (y & 1) ? 0x04000100u : 0x00040001u, 0u) << (8 * y);
+  // values 1 or 2 are counted at the end, two rows per dword (fields at bits (0, 1), (4, 5) of a byte | the next row's << 2)
   if (y == 0) A.u01 = u;
-  else if (y == 1) A.u01 |= u << 4;
+  else if (y == 1) A.u01 |= u << 2;
   else if (y == 2) A.u23 = u;
-  else A.u23 |= u << 4;
+  else A.u23 |= u << 2;
 }
 ICAMD_DEV uint32_t pvrtc_acc_finish(const PvrtcBlockAcc &A, bool *mode_1bpp) {
   // pixels best served by an intermediate value (1 or 2): low bit xor high bit of each 2-bit field
@@ -939,30 +940,31 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
     }
     if (s > K) break;
     // colour rows (s-1, s): V = 32 A, dV = 8 (B - A) -- see pvrtc_encode_strip
-    uint32_t V[3][4], dV[3][4];
-    ICAMD_UNROLL
-    for (int c = 0; c < 3; ++c) {
-      const uint32_t b[4] = { pair_rb(cc[c].a), pair_ga(cc[c].a), pair_rb(cc[c].b), pair_ga(cc[c].b) };
-      ICAMD_UNROLL
-      for (int v = 0; v < 4; ++v) {
-        V[c][v] = A[c][v] << 5;
-        dV[c][v] = (b[v] - A[c][v]) << 3;
-        A[c][v] = b[v];
-      }
-    }
 #if defined(ICAMD_PVRTC_WALK64)
-    // the same bases as 64-bit pairs (pvrtc_row_mods_pd64).  Set up word by word like the 32-bit form, then made exact modulo
-    // 2^64: the steps are SIGNED quantities below 2^31 in magnitude per word (lanes of at most 16 320), so the pair's high
-    // word owes the low word's sign -- hi + (lo >> 31, arithmetic); the P bases have non-negative lanes and need nothing.
+    // The bases of the horizontal walks and their steps per pixel row, straight from the colour rows A (s-1) and B (s), E = B - A:
+    //   left half row:  D = V[1] - V[0] = 32 (A1 - A0),  P = 4 (V[0] + V[1]) = 128 (A0 + A1);   per row + 8 (E1 - E0), + 32 (E0 + E1)
+    //   right half row: D = V[2] - V[1] = 32 (A2 - A1),  P = 8 V[1] = 256 A1;                   per row + 8 (E2 - E1), + 64 E1
+    // (sums / shifts commute modulo 2^32: the same words as deriving them from V and dV, 15 instead of 19 instructions per
+    // channel pair), then as 64-bit pairs (pvrtc_row_mods_pd64) made exact modulo 2^64: the steps are SIGNED quantities below
+    // 2^31 in magnitude per word (lanes of at most 16 320), so the pair's high word owes the low word's sign --
+    // hi + (lo >> 31, arithmetic); the P bases have non-negative lanes and need nothing.
     icamd_u64 P0[2], D0[2], P1[2], D1[2], dP0[2], dD0[2], dP1[2], dD1[2];
     {
       uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
       ICAMD_UNROLL
       for (int v = 0; v < 4; ++v) {
-        d0[v] = V[1][v] - V[0][v];        ed0[v] = dV[1][v] - dV[0][v];
-        p0[v] = (V[0][v] + V[1][v]) << 2; ep0[v] = (dV[0][v] + dV[1][v]) << 2;
-        d1[v] = V[2][v] - V[1][v];        ed1[v] = dV[2][v] - dV[1][v];
-        p1[v] = V[1][v] << 3;             ep1[v] = dV[1][v] << 3;
+        uint32_t a[3], e[3];
+        ICAMD_UNROLL
+        for (int c = 0; c < 3; ++c) {
+          const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
+          a[c] = A[c][v];
+          e[c] = b - a[c];
+          A[c][v] = b;
+        }
+        d0[v] = (a[1] - a[0]) << 5;  ed0[v] = (e[1] - e[0]) << 3;
+        p0[v] = (a[0] + a[1]) << 7;  ep0[v] = (e[0] + e[1]) << 5;
+        d1[v] = (a[2] - a[1]) << 5;  ed1[v] = (e[2] - e[1]) << 3;
+        p1[v] = a[1] << 8;           ep1[v] = e[1] << 6;
       }
       ICAMD_UNROLL
       for (int p = 0; p < 2; ++p) {
@@ -979,7 +981,19 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
     P0[p] = add64(P0[p], dP0[p]); D0[p] = add64(D0[p], dD0[p]);                                              \
     P1[p] = add64(P1[p], dP1[p]); D1[p] = add64(D1[p], dD1[p]);                                              \
   }
-#elif !defined(ICAMD_PVRTC_ONEPASS_STEP_V)
+#else
+    uint32_t V[3][4], dV[3][4];
+    ICAMD_UNROLL
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t b[4] = { pair_rb(cc[c].a), pair_ga(cc[c].a), pair_rb(cc[c].b), pair_ga(cc[c].b) };
+      ICAMD_UNROLL
+      for (int v = 0; v < 4; ++v) {
+        V[c][v] = A[c][v] << 5;
+        dV[c][v] = (b[v] - A[c][v]) << 3;
+        A[c][v] = b[v];
+      }
+    }
+#if !defined(ICAMD_PVRTC_ONEPASS_STEP_V)
     // ... and from them the bases of the horizontal walks and THEIR steps per pixel row (pvrtc_row_mods_pd; everything is
     // linear in the vertical weight, and sums / shifts commute modulo 2^32, so stepping these equals re-deriving them):
     //   left half row:  D = V[1] - V[0],  P = 4 (V[0] + V[1]);     right half row:  D = V[2] - V[1],  P = 8 V[1]
@@ -1002,6 +1016,7 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
   for (int c = 0; c < 3; ++c)                                 \
     ICAMD_UNROLL                                              \
     for (int v = 0; v < 4; ++v) V[c][v] += dV[c][v];
+#endif
 #endif
     uint32_t row[2];
     if (s >= 1) {  // row 2 of block s-1, weight 0
@@ -1281,18 +1296,18 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
       uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
       ICAMD_UNROLL
       for (int v = 0; v < 4; ++v) {
-        uint32_t Vc[3], dVc[3];
+        uint32_t a[3], e[3];  // (straight from A and E = B - A, as in pvrtc_onepass_strip: V = 16 A, dV = 4 E)
         ICAMD_UNROLL
         for (int c = 0; c < 3; ++c) {
           const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
-          Vc[c] = A[c][v] << 4;
-          dVc[c] = (b - A[c][v]) << 2;
+          a[c] = A[c][v];
+          e[c] = b - a[c];
           A[c][v] = b;
         }
-        d0[v] = (Vc[1] - Vc[0]) << 2;   ed0[v] = (dVc[1] - dVc[0]) << 2;
-        p0[v] = (Vc[0] + Vc[1]) << 3;   ep0[v] = (dVc[0] + dVc[1]) << 3;
-        d1[v] = (Vc[2] - Vc[1]) << 2;   ed1[v] = (dVc[2] - dVc[1]) << 2;
-        p1[v] = Vc[1] << 4;             ep1[v] = dVc[1] << 4;
+        d0[v] = (a[1] - a[0]) << 6;  ed0[v] = (e[1] - e[0]) << 4;
+        p0[v] = (a[0] + a[1]) << 7;  ep0[v] = (e[0] + e[1]) << 5;
+        d1[v] = (a[2] - a[1]) << 6;  ed1[v] = (e[2] - e[1]) << 4;
+        p1[v] = a[1] << 8;           ep1[v] = e[1] << 6;
       }
       ICAMD_UNROLL
       for (int p = 0; p < 2; ++p) {  // (signed steps: lanes of at most 16 320 -- see pvrtc_onepass_strip)

@@ -725,7 +725,10 @@ __device__ __forceinline__ void pvrtc2_onepass_body(const PvrtcLaunch &L, uint32
     const uint32_t base = ring_lane_byte + ((uint32_t)(cur_m - 3) & 7u) * 2048u;
     uint32_t a[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) a[i] = base + ((idx[i] & 28u) << 8) + ((idx[i] & 3u) << 2);
+    for (int i = 0; i < 10; ++i) {  // pixel idx = 8 y + x sits at (idx >> 2) * 1024 + (idx & 3) * 4: v_bfe, v_lshl_add, v_and, v_lshl_add
+      const uint32_t half_row = opaque(__builtin_amdgcn_ubfe(idx[i], 2u, 3u));  // (opaque: hipcc turns it back into shift + and + add + and_or)
+      a[i] = ((idx[i] & 3u) << 2) + ((half_row << 10) + base);
+    }
     asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %12\n\tds_read_b32 %3, %13\n\t"
                  "ds_read_b32 %4, %14\n\tds_read_b32 %5, %15\n\tds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\t"
                  "ds_read_b32 %8, %18\n\tds_read_b32 %9, %19\n\ts_waitcnt lgkmcnt(0)"
@@ -1224,7 +1227,10 @@ extern "C" __global__ void __launch_bounds__(1024) icamd_pvrtc4_onepass_kernel(P
     const uint32_t base = ring_lane_byte + ((uint32_t)(cur_m - 3) & 7u) * 1024u;
     uint32_t a[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) a[i] = base + ((idx[i] & 12u) << 8) + ((idx[i] & 3u) << 2);
+    for (int i = 0; i < 10; ++i) {  // pixel idx = 4 y + x sits at y * 1024 + x * 4 (see the 2 bpp kernel's lookup)
+      const uint32_t y = opaque(__builtin_amdgcn_ubfe(idx[i], 2u, 2u));
+      a[i] = ((idx[i] & 3u) << 2) + ((y << 10) + base);
+    }
     asm volatile("ds_read_b32 %0, %10\n\tds_read_b32 %1, %11\n\tds_read_b32 %2, %12\n\tds_read_b32 %3, %13\n\t"
                  "ds_read_b32 %4, %14\n\tds_read_b32 %5, %15\n\tds_read_b32 %6, %16\n\tds_read_b32 %7, %17\n\t"
                  "ds_read_b32 %8, %18\n\tds_read_b32 %9, %19\n\ts_waitcnt lgkmcnt(0)"
