@@ -840,13 +840,15 @@ ICAMD_DEV void pvrtc_keys_row(PvrtcMorphKeys &k, const uint32_t px[8]) {
       kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
       const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16);
       const uint32_t k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
-      k.min_rb = pk_min_u16(k.min_rb, k_rb);
-      k.min_ga = pk_min_u16(k.min_ga, k_ga);
+      // (pixel 0 of a block ASSIGNS the running keys: the reset values -- all ones / zero -- never win against a key)
+      k.min_rb = p == 0 ? k_rb : pk_min_u16(k.min_rb, k_rb);
+      k.min_ga = p == 0 ? k_ga : pk_min_u16(k.min_ga, k_ga);
       pvrtc_keys_max_step<32>(k, p, k_rb, k_ga);
     }
     const int p = 8 * Q + x;
-    k.min_l = umin3(k.min_l, kl[0], kl[1]);
-    k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(31 - 2 * p), kl[1] + (uint32_t)(31 - 2 * (p + 1)));
+    k.min_l = p == 0 ? umin(kl[0], kl[1]) : umin3(k.min_l, kl[0], kl[1]);
+    k.max_l = p == 0 ? umax(kl[0] + 31u, kl[1] + 29u)
+                     : umax3(k.max_l, kl[0] + (uint32_t)(31 - 2 * p), kl[1] + (uint32_t)(31 - 2 * (p + 1)));
   }
   pvrtc_keys_opaque(k);
   ICAMD_SCHED_FENCE();
@@ -919,6 +921,9 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
   tick(-3, mp, ep); pvrtc_keys_row<1>(keys, mp);
   tick(-2, mp, ep); pvrtc_keys_row<2>(keys, mp);
   PvrtcColors cc[3] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+#if defined(ICAMD_PVRTC_WALK64)
+  icamd_u64 P0[2] = { 0u, 0u }, D0[2] = { 0u, 0u }, P1[2] = { 0u, 0u }, D1[2] = { 0u, 0u };  // the walks' bases, carried
+#endif
   ICAMD_NOUNROLL
   for (int s = -1;; ++s) {
     if (s <= K) {
@@ -948,28 +953,28 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
     // channel pair), then as 64-bit pairs (pvrtc_row_mods_pd64) made exact modulo 2^64: the steps are SIGNED quantities below
     // 2^31 in magnitude per word (lanes of at most 16 320), so the pair's high word owes the low word's sign --
     // hi + (lo >> 31, arithmetic); the P bases have non-negative lanes and need nothing.
-    icamd_u64 P0[2], D0[2], P1[2], D1[2], dP0[2], dD0[2], dP1[2], dD1[2];
+    // The bases themselves are CARRIED from segment to segment: four row steps lead from colour row s-1 to colour row s, so
+    // a fourth ICAMD_ROW_STEP at the end of the segment leaves exactly the next segment's bases (32 (B1 - B0) = 32 (A1 - A0)
+    // + 4 * 8 (E1 - E0), ...; zero before the first segment, like A) -- 8 pair adds instead of deriving them from A again.
+    icamd_u64 dP0[2], dD0[2], dP1[2], dD1[2];
     {
-      uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
+      uint32_t ep0[4], ed0[4], ep1[4], ed1[4];
       ICAMD_UNROLL
       for (int v = 0; v < 4; ++v) {
-        uint32_t a[3], e[3];
+        uint32_t e[3];
         ICAMD_UNROLL
         for (int c = 0; c < 3; ++c) {
           const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
-          a[c] = A[c][v];
-          e[c] = b - a[c];
+          e[c] = b - A[c][v];
           A[c][v] = b;
         }
-        d0[v] = (a[1] - a[0]) << 5;  ed0[v] = (e[1] - e[0]) << 3;
-        p0[v] = (a[0] + a[1]) << 7;  ep0[v] = (e[0] + e[1]) << 5;
-        d1[v] = (a[2] - a[1]) << 5;  ed1[v] = (e[2] - e[1]) << 3;
-        p1[v] = a[1] << 8;           ep1[v] = e[1] << 6;
+        ed0[v] = (e[1] - e[0]) << 3;
+        ep0[v] = (e[0] + e[1]) << 5;
+        ed1[v] = (e[2] - e[1]) << 3;
+        ep1[v] = e[1] << 6;
       }
       ICAMD_UNROLL
       for (int p = 0; p < 2; ++p) {
-        P0[p] = pack64(p0[2 * p], p0[2 * p + 1]);  P1[p] = pack64(p1[2 * p], p1[2 * p + 1]);
-        D0[p] = pack64_signed(d0[2 * p], d0[2 * p + 1]);    D1[p] = pack64_signed(d1[2 * p], d1[2 * p + 1]);
         dD0[p] = pack64_signed(ed0[2 * p], ed0[2 * p + 1]); dD1[p] = pack64_signed(ed1[2 * p], ed1[2 * p + 1]);
         dP0[p] = pack64_signed(ep0[2 * p], ep0[2 * p + 1]); dP1[p] = pack64_signed(ep1[2 * p], ep1[2 * p + 1]);
       }
@@ -1065,6 +1070,9 @@ ICAMD_DEV void pvrtc_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tic
       pvrtc_acc_row<true>(acc, 1, row, 0u);
       prev[0] = row[0]; prev[1] = row[1];
     }
+#if defined(ICAMD_PVRTC_WALK64)
+    ICAMD_ROW_STEP()  // weight 4 = colour row s itself = the next segment's weight 0
+#endif
     ICAMD_SCHED_FENCE();
   }
 }
@@ -1181,13 +1189,14 @@ ICAMD_DEV void pvrtc4_keys_row(PvrtcMorphKeys &k, const uint32_t px[4]) {
       const uint32_t idx4 = (uint32_t)(p & ~3) * 0x01010101u + 0x03020100u;
       kl[q] = perm(udot4(c, 0x001c964du, 0u), idx4, 0x0c0c0500u | i);
       const uint32_t k_rb = perm(c, idx4, 0x06000400u | i | i << 16), k_ga = perm(c, idx4, 0x07000500u | i | i << 16);
-      k.min_rb = pk_min_u16(k.min_rb, k_rb);
-      k.min_ga = pk_min_u16(k.min_ga, k_ga);
+      k.min_rb = p == 0 ? k_rb : pk_min_u16(k.min_rb, k_rb);
+      k.min_ga = p == 0 ? k_ga : pk_min_u16(k.min_ga, k_ga);
       pvrtc_keys_max_step<16>(k, p, k_rb, k_ga);
     }
     const int p = 4 * Q + x;
-    k.min_l = umin3(k.min_l, kl[0], kl[1]);
-    k.max_l = umax3(k.max_l, kl[0] + (uint32_t)(15 - 2 * p), kl[1] + (uint32_t)(15 - 2 * (p + 1)));
+    k.min_l = p == 0 ? umin(kl[0], kl[1]) : umin3(k.min_l, kl[0], kl[1]);
+    k.max_l = p == 0 ? umax(kl[0] + 15u, kl[1] + 13u)
+                     : umax3(k.max_l, kl[0] + (uint32_t)(15 - 2 * p), kl[1] + (uint32_t)(15 - 2 * (p + 1)));
   }
   pvrtc_keys_opaque(k);
   ICAMD_SCHED_FENCE();
@@ -1276,6 +1285,9 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
   tick(-3, mp, ep); pvrtc4_keys_row<1>(keys, mp);
   tick(-2, mp, ep); pvrtc4_keys_row<2>(keys, mp);
   PvrtcColors cc[3] = { { 0u, 0u }, { 0u, 0u }, { 0u, 0u } };
+#if defined(ICAMD_PVRTC_WALK64)
+  icamd_u64 P0[2] = { 0u, 0u }, D0[2] = { 0u, 0u }, P1[2] = { 0u, 0u }, D1[2] = { 0u, 0u };  // the walks' bases, carried
+#endif
   ICAMD_NOUNROLL
   for (int s = -1;; ++s) {
     {
@@ -1291,28 +1303,27 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
     // colour rows (s-1, s): V = 16 A + w * 4 (B - A) for weight w = 0..3; from it the walks' bases and their steps per pixel row:
     //   x = 0, 1: D = 4 (V[1] - V[0]), P = 8 (V[0] + V[1]);   x = 2, 3: D = 4 (V[2] - V[1]), P = 16 V[1]
 #if defined(ICAMD_PVRTC_WALK64)
-    icamd_u64 P0[2], D0[2], P1[2], D1[2], dP0[2], dD0[2], dP1[2], dD1[2];
+    // (the bases are carried and stepped a fourth time at the end of the segment, the steps come straight from E = B - A: see
+    // pvrtc_onepass_strip; here D = 64 (A1 - A0), P = 128 (A0 + A1) | D = 64 (A2 - A1), P = 256 A1)
+    icamd_u64 dP0[2], dD0[2], dP1[2], dD1[2];
     {
-      uint32_t p0[4], d0[4], p1[4], d1[4], ep0[4], ed0[4], ep1[4], ed1[4];
+      uint32_t ep0[4], ed0[4], ep1[4], ed1[4];
       ICAMD_UNROLL
       for (int v = 0; v < 4; ++v) {
-        uint32_t a[3], e[3];  // (straight from A and E = B - A, as in pvrtc_onepass_strip: V = 16 A, dV = 4 E)
+        uint32_t e[3];
         ICAMD_UNROLL
         for (int c = 0; c < 3; ++c) {
           const uint32_t b = v == 0 ? pair_rb(cc[c].a) : v == 1 ? pair_ga(cc[c].a) : v == 2 ? pair_rb(cc[c].b) : pair_ga(cc[c].b);
-          a[c] = A[c][v];
-          e[c] = b - a[c];
+          e[c] = b - A[c][v];
           A[c][v] = b;
         }
-        d0[v] = (a[1] - a[0]) << 6;  ed0[v] = (e[1] - e[0]) << 4;
-        p0[v] = (a[0] + a[1]) << 7;  ep0[v] = (e[0] + e[1]) << 5;
-        d1[v] = (a[2] - a[1]) << 6;  ed1[v] = (e[2] - e[1]) << 4;
-        p1[v] = a[1] << 8;           ep1[v] = e[1] << 6;
+        ed0[v] = (e[1] - e[0]) << 4;
+        ep0[v] = (e[0] + e[1]) << 5;
+        ed1[v] = (e[2] - e[1]) << 4;
+        ep1[v] = e[1] << 6;
       }
       ICAMD_UNROLL
-      for (int p = 0; p < 2; ++p) {  // (signed steps: lanes of at most 16 320 -- see pvrtc_onepass_strip)
-        P0[p] = pack64(p0[2 * p], p0[2 * p + 1]);  P1[p] = pack64(p1[2 * p], p1[2 * p + 1]);
-        D0[p] = pack64_signed(d0[2 * p], d0[2 * p + 1]);    D1[p] = pack64_signed(d1[2 * p], d1[2 * p + 1]);
+      for (int p = 0; p < 2; ++p) {  // (signed steps: lanes of at most 16 320)
         dD0[p] = pack64_signed(ed0[2 * p], ed0[2 * p + 1]); dD1[p] = pack64_signed(ed1[2 * p], ed1[2 * p + 1]);
         dP0[p] = pack64_signed(ep0[2 * p], ep0[2 * p + 1]); dP1[p] = pack64_signed(ep1[2 * p], ep1[2 * p + 1]);
       }
@@ -1366,6 +1377,9 @@ ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &ti
     tick(4 * s + 6, mp, ep);
     pvrtc4_keys_row<2>(keys, mp);
     if (s >= 0) data |= ICAMD_ROW4_BITS(ep) << 8;  // row 1 of block s, weight 3
+#if defined(ICAMD_PVRTC_WALK64)
+    ICAMD_ROW4_STEP()  // weight 4 = colour row s itself = the next segment's weight 0
+#endif
 #undef ICAMD_ROW4_STEP
 #undef ICAMD_ROW4_BITS
   }
