@@ -360,7 +360,21 @@ ICAMD_DEV void pvrtc_row_mods_pd(const uint32_t P0[4], const uint32_t D0[4], con
 #define ICAMD_PVRTC_WALK64 1
 #endif
 typedef unsigned long long icamd_u64;
+#if defined(ICAMD_HOST_EMULATION)
 ICAMD_DEV icamd_u64 pack64(uint32_t lo, uint32_t hi) { return (icamd_u64)hi << 32 | lo; }
+ICAMD_DEV uint32_t lo32(icamd_u64 v) { return (uint32_t)v; }
+ICAMD_DEV uint32_t hi32(icamd_u64 v) { return (uint32_t)(v >> 32); }
+#else
+// (as a two-element vector: hipcc then keeps the pair in one aligned register pair whose halves are written in place; the
+// shift-and-or form is canonicalised to zext(lo) + (hi << 32) and a pair add becomes v_lshl_add_u64 + v_add_u32)
+typedef uint32_t icamd_u32x2 __attribute__((ext_vector_type(2)));
+ICAMD_DEV icamd_u64 pack64(uint32_t lo, uint32_t hi) {
+  const icamd_u32x2 v = { lo, hi };
+  return __builtin_bit_cast(icamd_u64, v);
+}
+ICAMD_DEV uint32_t lo32(icamd_u64 v) { return __builtin_bit_cast(icamd_u32x2, v).x; }
+ICAMD_DEV uint32_t hi32(icamd_u64 v) { return __builtin_bit_cast(icamd_u32x2, v).y; }
+#endif
 // the pair of two SIGNED words (each below 2^31 in magnitude, given modulo 2^32) as hi * 2^32 + lo modulo 2^64
 ICAMD_DEV icamd_u64 pack64_signed(uint32_t lo, uint32_t hi) { return pack64(lo, hi + (uint32_t)((int32_t)lo >> 31)); }
 template <int S>
@@ -391,7 +405,7 @@ ICAMD_DEV void pvrtc_row_mods_pd64(const icamd_u64 P0[2], const icamd_u64 D0[2],
     uint32_t acc = 0;
     ICAMD_UNROLL
     for (int j = 0; j < 4; ++j) {
-      const uint32_t P[4] = { (uint32_t)Q[0], (uint32_t)(Q[0] >> 32), (uint32_t)Q[1], (uint32_t)(Q[1] >> 32) };
+      const uint32_t P[4] = { lo32(Q[0]), hi32(Q[0]), lo32(Q[1]), hi32(Q[1]) };
       acc = opaque(accumulate_mod(pixels[4 * h + j], P, 1u << (8 * j), acc));
       ICAMD_SCHED_FENCE();
       if (j < 3) {
@@ -804,7 +818,7 @@ ICAMD_DEV void pvrtc_keys_max_step(PvrtcMorphKeys &k, int P, uint32_t k_rb, uint
     k.max_pair = pack64(k_rb, k_ga);
   } else {
     const icamd_u64 m = add64(k.max_pair, pack64(0x00020002u, 0x00020002u));
-    k.max_pair = pack64(pk_max_u16((uint32_t)m, k_rb), pk_max_u16((uint32_t)(m >> 32), k_ga));
+    k.max_pair = pack64(pk_max_u16(lo32(m), k_rb), pk_max_u16(hi32(m), k_ga));
   }
 #endif
 }
@@ -814,8 +828,8 @@ ICAMD_DEV void pvrtc_keys_max_words(const PvrtcMorphKeys &k, uint32_t &max_rb, u
   max_rb = k.max_rb;
   max_ga = k.max_ga;
 #else
-  max_rb = (uint32_t)k.max_pair - (uint32_t)(N - 1) * 0x00010001u;
-  max_ga = (uint32_t)(k.max_pair >> 32) - (uint32_t)(N - 1) * 0x00010001u;
+  max_rb = lo32(k.max_pair) - (uint32_t)(N - 1) * 0x00010001u;
+  max_ga = hi32(k.max_pair) - (uint32_t)(N - 1) * 0x00010001u;
 #endif
 }
 ICAMD_DEV void pvrtc_keys_opaque(PvrtcMorphKeys &k) {
@@ -1256,7 +1270,7 @@ ICAMD_DEV uint32_t pvrtc4_row_bits64(const icamd_u64 P0[2], const icamd_u64 D0[2
     icamd_u64 Q[2] = { Pb[0], Pb[1] };
     ICAMD_UNROLL
     for (int j = 0; j < 2; ++j) {
-      const uint32_t P[4] = { (uint32_t)Q[0], (uint32_t)(Q[0] >> 32), (uint32_t)Q[1], (uint32_t)(Q[1] >> 32) };
+      const uint32_t P[4] = { lo32(Q[0]), hi32(Q[0]), lo32(Q[1]), hi32(Q[1]) };
       acc = opaque(accumulate_mod(px[2 * h + j], P, 1u << (16 * h + 8 * j), acc));
       ICAMD_SCHED_FENCE();
       if (j == 0) {

@@ -607,11 +607,13 @@ constexpr uint32_t kOnePassChunkSlots = 18;                                  // 
 constexpr uint32_t kOnePassWaveDwords = kOnePassRing * 512u + 16u * kOnePassChunkSlots * 2u;  // ring + tile: 18 688 bytes
 constexpr uint32_t kOnePassXchDwords = 8;                                    // per wave and parity: [lo.a lo.b col0 - | hi.a hi.b - -]
 
-__device__ __forceinline__ uint32_t dpp_from_lower_lane(uint32_t v) {  // lane i <- lane i - 1 (wave_shr:1); lane 0 keeps v
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+// lane i <- v of lane i - 1 (wave_shr:1); lane 0, which has no source lane, keeps `edge` (the DPP "old" operand: no select after it)
+__device__ __forceinline__ uint32_t dpp_from_lower_lane(uint32_t v, uint32_t edge) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false);
 }
-__device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {  // lane i <- lane i + 1 (wave_shl:1); lane 63 keeps v
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+// lane i <- v of lane i + 1 (wave_shl:1); lane 63 keeps `edge`
+__device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v, uint32_t edge) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false);
 }
 
 // HALO (r06): the workgroup covers 2^log2_wgc block columns of a WIDER rectangle -- a whole texture of 8192^2 and more, whose block
@@ -751,11 +753,10 @@ __device__ __forceinline__ void pvrtc2_onepass_body(const PvrtcLaunch &L, uint32
     const uint32_t al = HALO && wave_s == 0u ? halo_left_byte + (uint32_t)(s + 1) * 8u - 16u : x + left_wave * (kOnePassXchDwords * 4u);
     const uint32_t ar = HALO && wave_s + 1u == W ? halo_right_byte + (uint32_t)(s + 1) * 16u : x + right_wave * (kOnePassXchDwords * 4u);
     asm volatile("ds_read_b64 %0, %2 offset:16\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(r) : "v"(al), "v"(ar) : "memory");
-    const uint32_t la = dpp_from_lower_lane(own.a), lb = dpp_from_lower_lane(own.b);
-    const uint32_t ra = dpp_from_upper_lane(own.a), rb = dpp_from_upper_lane(own.b), rc = dpp_from_upper_lane(col0);
-    left.a = lane == 0u ? l.x : la;   left.b = lane == 0u ? l.y : lb;
-    right.a = lane == 63u ? r.x : ra; right.b = lane == 63u ? r.y : rb;
-    right_col0 = lane == 63u ? r.z : rc;
+    // (every lane has read the same two records; only the edge lanes keep them)
+    left.a = dpp_from_lower_lane(own.a, l.x);   left.b = dpp_from_lower_lane(own.b, l.y);
+    right.a = dpp_from_upper_lane(own.a, r.x);  right.b = dpp_from_upper_lane(own.b, r.y);
+    right_col0 = dpp_from_upper_lane(col0, r.z);
   };
   // this lane's slot of block row jj (0..3) in the wave's tile: chunk = lane / 4, Z order inside (x odd bits, y even bits)
   const uint32_t tile_lane_byte = tile_byte + ((lane >> 2) * kOnePassChunkSlots + (((lane & 1u) | (lane & 2u) << 1) << 1)) * 8u;
@@ -1250,10 +1251,8 @@ extern "C" __global__ void __launch_bounds__(1024) icamd_pvrtc4_onepass_kernel(P
     uint2 l, r;
     const uint32_t al = x + left_wave * (kOnePass4XchDwords * 4u), ar = x + right_wave * (kOnePass4XchDwords * 4u);
     asm volatile("ds_read_b64 %0, %2 offset:8\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(l), "=&v"(r) : "v"(al), "v"(ar) : "memory");
-    const uint32_t la = dpp_from_lower_lane(own.a), lb = dpp_from_lower_lane(own.b);
-    const uint32_t ra = dpp_from_upper_lane(own.a), rb = dpp_from_upper_lane(own.b);
-    left.a = lane == 0u ? l.x : la;   left.b = lane == 0u ? l.y : lb;
-    right.a = lane == 63u ? r.x : ra; right.b = lane == 63u ? r.y : rb;
+    left.a = dpp_from_lower_lane(own.a, l.x);   left.b = dpp_from_lower_lane(own.b, l.y);
+    right.a = dpp_from_upper_lane(own.a, r.x);  right.b = dpp_from_upper_lane(own.b, r.y);
   };
   // tile: chunk = lane / 2 (two block columns x two block rows = four consecutive Z slots = 32 bytes)
   const uint32_t tile_lane_byte = tile_byte + ((lane >> 1) * 4u + ((lane & 1u) << 1)) * 8u;
