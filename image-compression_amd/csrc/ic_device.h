@@ -86,6 +86,7 @@ ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) {
   }
   return c;
 }
+ICAMD_DEV uint32_t sad_hi_u8(uint32_t a, uint32_t b, uint32_t c) { return (sad_u8(a, b, 0u) << 16) + c; }
 ICAMD_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31));
 }
@@ -127,6 +128,7 @@ ICAMD_DEV uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t c) { return __builti
 ICAMD_DEV uint32_t sad_u16x2(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u16(a, b, c); }
 // v_sad_u8: sum over the 4 bytes of |a.b - b.b|, plus c
 ICAMD_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_u8(a, b, c); }
+ICAMD_DEV uint32_t sad_hi_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_sad_hi_u8(a, b, c); }  // (sad << 16) + c
 // v_lerp_u8 with a zero rounding operand: per byte (a + b) >> 1 -- four floor-averages in one instruction
 ICAMD_DEV uint32_t avg_u8(uint32_t a, uint32_t b) { return __builtin_amdgcn_lerp(a, b, 0u); }
 // v_alignbit_b32: low 32 bits of ({hi,lo} >> sh)

@@ -268,6 +268,28 @@ ICAMD_DEV uint32_t scan_into_byte(uint32_t d0, uint32_t d1, uint32_t d2, uint32_
   return acc + ((uint32_t)s1 + (uint32_t)s2 + (uint32_t)s3) * unit;
 }
 #endif
+// ---- two pixels per scan (r06) ----------------------------------------------------------------------------------------------
+// The four L1 distances of a pixel are at most 1 020, so TWO pixels' distances share a dword: v_sad_u8 writes the first pixel's
+// into the low half, v_sad_hi_u8 ((sad << 16) + accumulator) adds the second pixel's on top -- still one instruction per distance.
+// The early-exit scan then runs on both 16-bit lanes at once: the sign bit of d(k+1) - d(k) (v_pk_sub_u16, |difference| < 2^15)
+// is "step k + 1 improves", the chain s1, s1 && s2, s1 && s2 && s3 is two ANDs on the raw differences, and the value 0 .. 3 is
+// the sum of the three sign bits -- 9 instructions for two pixels where the compare / select chain takes 12, no VCC, no inline
+// asm (hipcc follows every asm statement with an s_nop).  Same decisions as best_modulation().  -DICAMD_PVRTC_SCAN_SDWA keeps
+// the one-pixel form.
+ICAMD_DEV void modulation_colours(const uint32_t P[4], uint32_t c[4]) {
+  const uint32_t kSel = 0x07030501u;  // bytes: lo.b1, hi.b1, lo.b3, hi.b3  = R, G, B, A
+  c[0] = perm(P[1], P[0], kSel);
+  c[3] = perm(P[3], P[2], kSel);
+  const uint32_t m = avg_u8(c[0], c[3]);
+  c[1] = avg_u8(c[0], avg_u8(c[3], m));
+  c[2] = avg_u8(c[3], avg_u8(c[0], m));
+}
+// d[k]: distances of two pixels to their own colour k, one per 16-bit lane -> the two modulation values, one per lane
+ICAMD_DEV uint32_t scan_pair(const uint32_t d[4]) {
+  const uint32_t s1 = pk_sub_u16(d[1], d[0]), s2 = pk_sub_u16(d[2], d[1]), s3 = pk_sub_u16(d[3], d[2]);
+  const uint32_t s12 = s1 & s2, s123 = s12 & s3;
+  return pk_lshr16(s1, 15) + pk_lshr16(s12, 15) + pk_lshr16(s123, 15);
+}
 ICAMD_DEV uint32_t accumulate_mod(uint32_t pixel, const uint32_t P[4], uint32_t unit, uint32_t acc) {
   const uint32_t kSel = 0x07030501u;  // bytes: lo.b1, hi.b1, lo.b3, hi.b3  = R, G, B, A
   const uint32_t c0 = perm(P[1], P[0], kSel), c3 = perm(P[3], P[2], kSel);
@@ -402,6 +424,7 @@ ICAMD_DEV void pvrtc_row_mods_pd64(const icamd_u64 P0[2], const icamd_u64 D0[2],
   for (int h = 0; h < 2; ++h) {
     const icamd_u64 *Pb = h ? P1 : P0, *D = h ? D1 : D0;
     icamd_u64 Q[2] = { Pb[0], Pb[1] };
+#if defined(ICAMD_PVRTC_SCAN_SDWA)
     uint32_t acc = 0;
     ICAMD_UNROLL
     for (int j = 0; j < 4; ++j) {
@@ -414,6 +437,30 @@ ICAMD_DEV void pvrtc_row_mods_pd64(const icamd_u64 P0[2], const icamd_u64 D0[2],
       }
     }
     row[h] = acc;
+#else
+    // pixels (0, 2) and (1, 3) of the half row share their scans: the values land in bytes 0, 2 of one word and, shifted, 1, 3
+    uint32_t d[2][4], val[2] = { 0u, 0u };
+    ICAMD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t P[4] = { lo32(Q[0]), hi32(Q[0]), lo32(Q[1]), hi32(Q[1]) };
+      uint32_t c[4];
+      modulation_colours(P, c);
+      const uint32_t px = pixels[4 * h + j];
+      ICAMD_UNROLL
+      for (int k = 0; k < 4; ++k) d[j & 1][k] = j < 2 ? sad_u8(px, c[k], 0u) : sad_hi_u8(px, c[k], d[j & 1][k]);
+      if (j >= 2) val[j & 1] = opaque(scan_pair(d[j & 1]));
+      else {
+        ICAMD_UNROLL
+        for (int k = 0; k < 4; ++k) d[j][k] = opaque(d[j][k]);
+      }
+      ICAMD_SCHED_FENCE();
+      if (j < 3) {
+        Q[0] = add64(Q[0], D[0]);
+        Q[1] = add64(Q[1], D[1]);
+      }
+    }
+    row[h] = val[0] | val[1] << 8;
+#endif
   }
 }
 
@@ -1263,6 +1310,9 @@ ICAMD_DEV uint32_t pvrtc4_row_bits(const uint32_t P0[4], const uint32_t D0[4], c
 // ... with the bases as 64-bit pairs (see pvrtc_row_mods_pd64)
 ICAMD_DEV uint32_t pvrtc4_row_bits64(const icamd_u64 P0[2], const icamd_u64 D0[2], const icamd_u64 P1[2], const icamd_u64 D1[2],
                                      const uint32_t px[4]) {
+  // (one-pixel scans here: at this kernel's four waves per SIMD the compare / select chain is the cheaper one -- the two-pixel
+  // form of pvrtc_row_mods_pd64, -DICAMD_PVRTC4_SCAN_PAIR, measured 0.4167 -> 0.4244 ms on 16 x 4096^2)
+#if !defined(ICAMD_PVRTC4_SCAN_PAIR)
   uint32_t acc = 0;
   ICAMD_UNROLL
   for (int h = 0; h < 2; ++h) {
@@ -1280,6 +1330,35 @@ ICAMD_DEV uint32_t pvrtc4_row_bits64(const icamd_u64 P0[2], const icamd_u64 D0[2
     }
   }
   return udot4(acc, 0x40100401u, 0u);
+#else
+  // pixels (0, 2) and (1, 3) of the row share their scans (scan_pair): values in bytes 0, 2 and, shifted, 1, 3
+  uint32_t d[2][4], val[2] = { 0u, 0u };
+  ICAMD_UNROLL
+  for (int h = 0; h < 2; ++h) {
+    const icamd_u64 *Pb = h ? P1 : P0, *D = h ? D1 : D0;
+    icamd_u64 Q[2] = { Pb[0], Pb[1] };
+    ICAMD_UNROLL
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t P[4] = { lo32(Q[0]), hi32(Q[0]), lo32(Q[1]), hi32(Q[1]) };
+      uint32_t c[4];
+      modulation_colours(P, c);
+      const uint32_t pixel = px[2 * h + j];
+      ICAMD_UNROLL
+      for (int k = 0; k < 4; ++k) d[j][k] = h == 0 ? sad_u8(pixel, c[k], 0u) : sad_hi_u8(pixel, c[k], d[j][k]);
+      if (h == 1) val[j] = opaque(scan_pair(d[j]));
+      else {
+        ICAMD_UNROLL
+        for (int k = 0; k < 4; ++k) d[j][k] = opaque(d[j][k]);
+      }
+      ICAMD_SCHED_FENCE();
+      if (j == 0) {
+        Q[0] = add64(Q[0], D[0]);
+        Q[1] = add64(Q[1], D[1]);
+      }
+    }
+  }
+  return udot4(val[0] | val[1] << 8, 0x40100401u, 0u);
+#endif
 }
 template <typename Tick, typename Lookup10, typename Exchange, typename BlockStore>
 ICAMD_DEV void pvrtc4_onepass_strip(uint32_t k_blocks, uint32_t image0, Tick &tick, Lookup10 &lookup10, Exchange &exchange,
